@@ -1,0 +1,246 @@
+// Host plan builder (pure C++, shared by the HIP library and the CPU wave simulator).
+#include "ffc_plan.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "ffc_layout.h"
+
+namespace ffc {
+
+uint16_t f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  uint32_t r = 0x7fffu + ((u >> 16) & 1);
+  return (uint16_t)((u + r) >> 16);
+}
+float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+uint16_t f32_to_f16(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u : 0));
+  if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to inf (>= 65520)
+  if (ax < 0x33000001u) return (uint16_t)sign;               // rounds to zero (<= 2^-25)
+  int e = (int)(ax >> 23) - 127;
+  uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+  int shift;
+  uint32_t base;
+  if (e < -14) {  // subnormal half
+    shift = 13 + (-14 - e);
+    base = 0;
+  } else {
+    shift = 13;
+    base = (uint32_t)(e + 15) << 10;
+    m &= 0x7fffffu;
+  }
+  uint32_t q = m >> shift;
+  uint32_t rem = m & ((1u << shift) - 1);
+  uint32_t half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1))) q++;
+  return (uint16_t)(sign | (base + q));
+}
+float f16_to_f32(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  int e = (h >> 10) & 31;
+  uint32_t m = h & 0x3ffu;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) {
+      u = sign;
+    } else {
+      int sh = 0;
+      while (!(m & 0x400u)) { m <<= 1; sh++; }
+      m &= 0x3ffu;
+      u = sign | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+    }
+  } else if (e == 31) {
+    u = sign | 0x7f800000u | (m << 13);
+  } else {
+    u = sign | ((uint32_t)(e - 15 + 127) << 23) | (m << 13);
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+bool plan_factors(int N, int* n1, int* n2, int* n3) {
+  switch (N) {
+    case 256: *n1 = 1; *n2 = 16; *n3 = 16; return true;
+    case 512: *n1 = 1; *n2 = 16; *n3 = 32; return true;
+    case 1024: *n1 = 1; *n2 = 32; *n3 = 32; return true;
+    case 4096: *n1 = 16; *n2 = 16; *n3 = 16; return true;
+    case 8192: *n1 = 32; *n2 = 16; *n3 = 16; return true;
+    case 16384: *n1 = 16; *n2 = 32; *n3 = 32; return true;
+    case 32768: *n1 = 32; *n2 = 32; *n3 = 32; return true;
+  }
+  return false;
+}
+
+namespace {
+
+const double kPi = 3.14159265358979323846;
+
+struct Builder {
+  std::vector<uint8_t>& b;
+  int alloc(int bytes) {
+    int off = (int)b.size();
+    b.resize(off + ((bytes + 255) & ~255), 0);
+    return off;
+  }
+};
+
+uint16_t to_dt(double v, int dtype) {
+  return dtype == DT_BF16 ? f32_to_bf16((float)v) : f32_to_f16((float)v);
+}
+
+// Operand table of the block-diagonal Nd-point DFT: [q = ms*3 + which][lane][d].
+void fill_mat(uint8_t* dst, int Nd, int dtype) {
+  uint32_t* w = (uint32_t*)dst;
+  for (int ms = 0; ms < 2; ms++)
+    for (int which = 0; which < 3; which++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int d = 0; d < 4; d++) {
+          uint32_t word = 0;
+          for (int half = 0; half < 2; half++) {
+            int e = 2 * d + half;
+            int nw = lane & 31, old = kslot_row(ms, lane >> 5, e);
+            double re = 0, im = 0;
+            if (nw / Nd == old / Nd) {
+              int k = nw % Nd, n = old % Nd;
+              double ang = -2.0 * kPi * (double)((n * k) % Nd) / Nd;
+              re = cos(ang);
+              im = sin(ang);
+            }
+            double v = which == 0 ? re : (which == 1 ? im : -im);
+            word |= (uint32_t)to_dt(v, dtype) << (16 * half);
+          }
+          w[((ms * 3 + which) * 64 + lane) * 4 + d] = word;
+        }
+}
+
+// ctab16: [rr 8][lane 64][re(2rr) im(2rr) re(2rr+1) im(2rr+1)]
+template <class F>
+void fill_ctab16(uint8_t* dst, F fn) {
+  float* w = (float*)dst;
+  for (int lane = 0; lane < 64; lane++)
+    for (int r = 0; r < 16; r++) {
+      double re, im;
+      fn(lane, r, &re, &im);
+      int rr = r >> 1, o = (r & 1) * 2;
+      w[(rr * 64 + lane) * 4 + o] = (float)re;
+      w[(rr * 64 + lane) * 4 + o + 1] = (float)im;
+    }
+}
+
+void cis(double num, double den, double scale, double* re, double* im) {
+  double ang = 2.0 * kPi * fmod(num, den) / den;
+  *re = scale * cos(ang);
+  *im = scale * sin(ang);
+}
+
+template <class GEO>
+void build(HostPlan* p) {
+  Builder bl{p->blob};
+  const int N = GEO::N;
+  p->NT = GEO::NT; p->NW = GEO::NW; p->G = GEO::G;
+  int lg = 0;
+  while ((1 << lg) < N) lg++;
+  p->s_fwd = ldexp(1.0, -((lg + 1) / 2));
+  p->s_k = 1.0 / ((double)N * p->s_fwd);
+  PlanTabs& t = p->tabs;
+  int digits[3] = {GEO::N1, GEO::N2, GEO::N3};
+  for (int i = 0; i < 3; i++) {
+    t.mat[i] = bl.alloc(6 * 64 * 16);
+    if (digits[i] > 1) fill_mat(p->blob.data() + t.mat[i], digits[i], p->dtype);
+  }
+  const double sf_inner = GEO::OUTER ? 1.0 : p->s_fwd;
+  t.twin = bl.alloc(8192);
+  fill_ctab16(p->blob.data() + t.twin, [&](int lane, int r, double* re, double* im) {
+    int k2 = (lane & 31) % GEO::N2, n3 = acc_row(r, lane >> 5) % GEO::N3;
+    cis(-(double)(n3 * k2), GEO::Mi, sf_inner, re, im);
+  });
+  t.twin2 = bl.alloc(8192);
+  fill_ctab16(p->blob.data() + t.twin2, [&](int lane, int r, double* re, double* im) {
+    int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
+    cis((double)(n3 * k2), GEO::Mi, 1.0, re, im);
+  });
+  t.base = bl.alloc(8192 * GEO::NW);
+  t.ct = bl.alloc(8192 * 4);
+  t.oi_a = bl.alloc(GEO::NT * 32 * GEO::SV * 8);
+  t.oi_b = bl.alloc(GEO::NT * GEO::SU * 2 * 16 * 8);
+  if (GEO::OUTER) {
+    for (int w = 0; w < GEO::NW; w++)
+      fill_ctab16(p->blob.data() + t.base + 8192 * w, [&](int lane, int r, double* re, double* im) {
+        int R = acc_row(r, lane >> 5), s1 = R / GEO::N1, k1 = R % GEO::N1, j = lane & 31;
+        int m = w * 128 * GEO::S1 + s1 * 128 + 4 * j;
+        cis(-(double)m * k1, N, p->s_fwd, re, im);
+      });
+    for (int tt = 0; tt < 4; tt++)
+      fill_ctab16(p->blob.data() + t.ct + 8192 * tt, [&](int lane, int r, double* re, double* im) {
+        int k1 = acc_row(r, lane >> 5) % GEO::N1;
+        cis(-(double)tt * k1, N, 1.0, re, im);
+      });
+    float* a = (float*)(p->blob.data() + t.oi_a);
+    float* bb = (float*)(p->blob.data() + t.oi_b);
+    for (int tau = 0; tau < GEO::NT; tau++) {
+      for (int c = 0; c < 32; c++)
+        for (int sV = 0; sV < GEO::SV; sV++) {
+          int sU = c / GEO::N2, n2 = c % GEO::N2;
+          int k1 = tau * GEO::G + sU * GEO::SV + sV;
+          double re, im;
+          cis((double)(n2 * GEO::N3) * k1, N, 1.0, &re, &im);
+          a[((tau * 32 + c) * GEO::SV + sV) * 2] = (float)re;
+          a[((tau * 32 + c) * GEO::SV + sV) * 2 + 1] = (float)im;
+        }
+      for (int sU = 0; sU < GEO::SU; sU++)
+        for (int hi = 0; hi < 2; hi++)
+          for (int r = 0; r < 16; r++) {
+            int V = acc_row(r, hi), sV = V / GEO::N3, n3 = V % GEO::N3;
+            int k1 = tau * GEO::G + sU * GEO::SV + sV;
+            double re, im;
+            cis((double)n3 * k1, N, 1.0, &re, &im);
+            int idx = ((tau * GEO::SU + sU) * 2 + hi) * 16 + r;
+            bb[idx * 2] = (float)re;
+            bb[idx * 2 + 1] = (float)im;
+          }
+    }
+  }
+  t.total = (int)p->blob.size();
+  p->kf_freq.resize((size_t)GEO::NT * 1024);
+  for (int tau = 0; tau < GEO::NT; tau++)
+    for (int rho = 0; rho < 8; rho++)
+      for (int U = 0; U < 32; U++)
+        for (int v = 0; v < 4; v++)
+          p->kf_freq[((tau * 8 + rho) * 32 + U) * 4 + v] = kf_freq<GEO>(tau, 4 * rho + v, U);
+}
+
+}  // namespace
+
+bool build_plan(int N, int dtype, HostPlan* p) {
+  int n1, n2, n3;
+  if (!plan_factors(N, &n1, &n2, &n3)) return false;
+  if (dtype != DT_BF16 && dtype != DT_F16) return false;
+  *p = HostPlan();
+  p->N = N; p->N1 = n1; p->N2 = n2; p->N3 = n3; p->dtype = dtype;
+  switch (N) {
+    case 256: build<Geo<1, 16, 16>>(p); break;
+    case 512: build<Geo<1, 16, 32>>(p); break;
+    case 1024: build<Geo<1, 32, 32>>(p); break;
+    case 4096: build<Geo<16, 16, 16>>(p); break;
+    case 8192: build<Geo<32, 16, 16>>(p); break;
+    case 16384: build<Geo<16, 32, 32>>(p); break;
+    case 32768: build<Geo<32, 32, 32>>(p); break;
+    default: return false;
+  }
+  return true;
+}
+
+}  // namespace ffc

@@ -1,0 +1,257 @@
+// CPU wave simulator: runs the very same kernel body (ffc_body.h) with a 64-lane vector backend,
+// one host thread per wavefront, pthread barrier = s_barrier, a byte array = LDS.
+// TEST INFRASTRUCTURE ONLY (tests/ and __graft_entry__.build use it); the product path is the
+// HIP library.  It models the gfx950 primitives the body relies on:
+//   v_mfma_f32_32x32x16_{bf16,f16} operand / accumulator lane layouts, ds_read_b64_tr_b16,
+//   RNE fp32->bf16/f16 packing, 8-byte predicated global accesses.
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <thread>
+#include <vector>
+
+#define FFC_FN inline __attribute__((always_inline))
+#include "ffc_body.h"
+#include "ffc_modes.h"
+
+namespace ffc {
+
+template <class T>
+struct Vec {
+  T v[64];
+  Vec() {}
+  Vec(T s) { for (int i = 0; i < 64; i++) v[i] = s; }
+};
+#define VOP(op)                                                                           \
+  template <class T> inline Vec<T> operator op(const Vec<T>& a, const Vec<T>& b) {        \
+    Vec<T> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b.v[i]; return r; }         \
+  template <class T> inline Vec<T> operator op(const Vec<T>& a, T b) {                    \
+    Vec<T> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] op b; return r; }              \
+  template <class T> inline Vec<T> operator op(T a, const Vec<T>& b) {                    \
+    Vec<T> r; for (int i = 0; i < 64; i++) r.v[i] = a op b.v[i]; return r; }
+VOP(+) VOP(-) VOP(*) VOP(/) VOP(%) VOP(&) VOP(|) VOP(^)
+#undef VOP
+template <class T> inline Vec<T> operator<<(const Vec<T>& a, int s) { Vec<T> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] << s; return r; }
+template <class T> inline Vec<T> operator>>(const Vec<T>& a, int s) { Vec<T> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >> s; return r; }
+// mixed u32 vector with int literal masks
+inline Vec<uint32_t> operator&(const Vec<uint32_t>& a, unsigned b) { Vec<uint32_t> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] & b; return r; }
+inline Vec<int> operator*(const Vec<int>& a, long b) { return a * (int)b; }
+inline Vec<bool> operator<(const Vec<int>& a, int b) { Vec<bool> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b; return r; }
+inline Vec<bool> operator<(const Vec<int>& a, const Vec<int>& b) { Vec<bool> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b.v[i]; return r; }
+inline Vec<bool> operator>=(const Vec<int>& a, int b) { Vec<bool> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] >= b; return r; }
+inline Vec<bool> operator&&(const Vec<bool>& a, const Vec<bool>& b) { Vec<bool> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
+inline Vec<bool> operator&&(const Vec<bool>& a, bool b) { Vec<bool> r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] && b; return r; }
+
+struct WgCtx {
+  std::vector<uint8_t> lds;
+  pthread_barrier_t bar;
+  int nwaves;
+};
+static thread_local WgCtx* g_wg = nullptr;
+static thread_local int g_wave = 0;
+
+static inline float dt_to_f32(int DT, uint16_t h) { return DT == DT_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
+static inline uint16_t f32_to_dt(int DT, float f) { return DT == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
+
+struct SimB {
+  using f32 = Vec<float>;
+  using i32 = Vec<int>;
+  using u32 = Vec<uint32_t>;
+  using pred = Vec<bool>;
+  struct U2 { u32 x, y; };
+  struct U4 { u32 x, y, z, w; };
+  static bool HAS_TR;
+
+  static i32 lane() { i32 r; for (int i = 0; i < 64; i++) r.v[i] = i; return r; }
+  static int wave() { return g_wave; }
+  static void barrier() { if (g_wg->nwaves > 1) pthread_barrier_wait(&g_wg->bar); }
+  static f32 fconst(float c) { return f32(c); }
+  static pred ptrue() { return pred(true); }
+  static pred pfalse() { return pred(false); }
+  static f32 as_f32(const u32& a) { f32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], &a.v[i], 4); return r; }
+  static u32 as_u32(const f32& a) { u32 r; for (int i = 0; i < 64; i++) memcpy(&r.v[i], &a.v[i], 4); return r; }
+
+  static uint8_t* L() { return g_wg->lds.data(); }
+  static void chk(int off, int n) { if (off < 0 || off + n > (int)g_wg->lds.size() || (off & (n - 1))) abort(); }
+  static U2 lds_r64(const i32& off) {
+    U2 r;
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 8); memcpy(&r.x.v[i], L() + off.v[i], 4); memcpy(&r.y.v[i], L() + off.v[i] + 4, 4); }
+    return r;
+  }
+  static void lds_w64(const i32& off, const U2& v) {
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 8); memcpy(L() + off.v[i], &v.x.v[i], 4); memcpy(L() + off.v[i] + 4, &v.y.v[i], 4); }
+  }
+  static U4 lds_r128(const i32& off) {
+    U4 r;
+    for (int i = 0; i < 64; i++) {
+      chk(off.v[i], 16);
+      memcpy(&r.x.v[i], L() + off.v[i], 4); memcpy(&r.y.v[i], L() + off.v[i] + 4, 4);
+      memcpy(&r.z.v[i], L() + off.v[i] + 8, 4); memcpy(&r.w.v[i], L() + off.v[i] + 12, 4);
+    }
+    return r;
+  }
+  static u32 lds_r16(const i32& off) {
+    u32 r;
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 2); uint16_t h; memcpy(&h, L() + off.v[i], 2); r.v[i] = h; }
+    return r;
+  }
+  // ds_read_b64_tr_b16: within each 16-lane group lane i' supplies the address of 4 b16 values
+  // M[i'][0..3]; lane i receives elements j=0..3 = M[4j + (i>>2)][i&3].
+  static U2 lds_r64_tr(const i32& off) {
+    U2 r;
+    for (int g = 0; g < 4; g++) {
+      uint16_t M[16][4];
+      for (int i = 0; i < 16; i++) { chk(off.v[g * 16 + i], 8); memcpy(M[i], L() + off.v[g * 16 + i], 8); }
+      for (int i = 0; i < 16; i++) {
+        uint16_t e[4];
+        for (int j = 0; j < 4; j++) e[j] = M[4 * j + (i >> 2)][i & 3];
+        r.x.v[g * 16 + i] = e[0] | ((uint32_t)e[1] << 16);
+        r.y.v[g * 16 + i] = e[2] | ((uint32_t)e[3] << 16);
+      }
+    }
+    return r;
+  }
+  static U2 g_r64(const void* base, const i32& o8, const pred& p) {
+    U2 r;
+    for (int i = 0; i < 64; i++) {
+      if (p.v[i]) { const uint8_t* q = (const uint8_t*)base + (int64_t)o8.v[i] * 8; memcpy(&r.x.v[i], q, 4); memcpy(&r.y.v[i], q + 4, 4); }
+      else { r.x.v[i] = 0; r.y.v[i] = 0; }
+    }
+    return r;
+  }
+  static void g_w64(void* base, const i32& o8, const U2& v, const pred& p) {
+    for (int i = 0; i < 64; i++)
+      if (p.v[i]) { uint8_t* q = (uint8_t*)base + (int64_t)o8.v[i] * 8; memcpy(q, &v.x.v[i], 4); memcpy(q + 4, &v.y.v[i], 4); }
+  }
+  static U4 g_r128(const void* base, const i32& o16) {
+    U4 r;
+    for (int i = 0; i < 64; i++) {
+      const uint8_t* q = (const uint8_t*)base + (int64_t)o16.v[i] * 16;
+      memcpy(&r.x.v[i], q, 4); memcpy(&r.y.v[i], q + 4, 4); memcpy(&r.z.v[i], q + 8, 4); memcpy(&r.w.v[i], q + 12, 4);
+    }
+    return r;
+  }
+  static U4 g_r128p(const void* base, const i32& o16, const pred& p) {
+    U4 r;
+    for (int i = 0; i < 64; i++) {
+      if (p.v[i]) {
+        const uint8_t* q = (const uint8_t*)base + (int64_t)o16.v[i] * 16;
+        memcpy(&r.x.v[i], q, 4); memcpy(&r.y.v[i], q + 4, 4); memcpy(&r.z.v[i], q + 8, 4); memcpy(&r.w.v[i], q + 12, 4);
+      } else { r.x.v[i] = r.y.v[i] = r.z.v[i] = r.w.v[i] = 0; }
+    }
+    return r;
+  }
+  static void g_w128(void* base, const i32& o16, const U4& v, const pred& p) {
+    for (int i = 0; i < 64; i++)
+      if (p.v[i]) {
+        uint8_t* q = (uint8_t*)base + (int64_t)o16.v[i] * 16;
+        memcpy(q, &v.x.v[i], 4); memcpy(q + 4, &v.y.v[i], 4); memcpy(q + 8, &v.z.v[i], 4); memcpy(q + 12, &v.w.v[i], 4);
+      }
+  }
+  // D[i][j] += sum_k A[i][k] B[k][j];  A lane l: A[l&31][8*(l>>5)+e];  B lane l: B[8*(l>>5)+e][l&31];
+  // D lane l reg r: D[acc_row(r, l>>5)][l&31].
+  template <int DT>
+  static void mfma(f32 (&acc)[16], const u32 (&a)[4], const u32 (&b)[4]) {
+    float A[32][16], Bm[16][32];
+    for (int l = 0; l < 64; l++)
+      for (int e = 0; e < 8; e++) {
+        uint16_t ha = (uint16_t)(a[e >> 1].v[l] >> (16 * (e & 1)));
+        uint16_t hb = (uint16_t)(b[e >> 1].v[l] >> (16 * (e & 1)));
+        A[l & 31][8 * (l >> 5) + e] = dt_to_f32(DT, ha);
+        Bm[8 * (l >> 5) + e][l & 31] = dt_to_f32(DT, hb);
+      }
+    for (int l = 0; l < 64; l++)
+      for (int r = 0; r < 16; r++) {
+        int i = acc_row(r, l >> 5), j = l & 31;
+        float s = 0;
+        for (int k = 0; k < 16; k++) s += A[i][k] * Bm[k][j];
+        acc[r].v[l] += s;
+      }
+  }
+  template <int DT> static u32 pack(const f32& lo, const f32& hi) {
+    u32 r;
+    for (int i = 0; i < 64; i++) r.v[i] = f32_to_dt(DT, lo.v[i]) | ((uint32_t)f32_to_dt(DT, hi.v[i]) << 16);
+    return r;
+  }
+  template <int DT> static f32 unpack_lo(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)a.v[i]); return r; }
+  template <int DT> static f32 unpack_hi(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)(a.v[i] >> 16)); return r; }
+};
+bool SimB::HAS_TR = true;
+
+// Run `fn(wg_index)` for one workgroup of nwaves wavefronts with lds_bytes of LDS.
+template <class F>
+static void run_wg(int nwaves, int lds_bytes, F fn) {
+  WgCtx ctx;
+  ctx.lds.assign(lds_bytes, 0xCD);
+  ctx.nwaves = nwaves;
+  pthread_barrier_init(&ctx.bar, nullptr, nwaves);
+  std::vector<std::thread> th;
+  for (int w = 0; w < nwaves; w++)
+    th.emplace_back([&, w]() { g_wg = &ctx; g_wave = w; fn(); });
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&ctx.bar);
+}
+
+template <class GEO, int DT>
+static void sim_conv_t(const ConvArgs& a) {
+  for (int h = 0; h < a.H; h++)
+    for (int c = 0; c < a.nchunk; c++)
+      run_wg(GEO::NW, GEO::EBYTES, [&]() { Body<SimB, GEO, DT>::conv(a, h, c); });
+}
+
+template <template <class, int> class FN, class... A>
+static int dispatch(int N, int dtype, A&&... args) {
+#define FFC_CASE(NN, a, b, c)                                                     \
+  case NN:                                                                        \
+    if (dtype == DT_BF16) FN<Geo<a, b, c>, DT_BF16>::run(args...);                \
+    else FN<Geo<a, b, c>, DT_F16>::run(args...);                                  \
+    return 0;
+  switch (N) {
+    FFC_CASE(256, 1, 16, 16)
+    FFC_CASE(512, 1, 16, 32)
+    FFC_CASE(1024, 1, 32, 32)
+    FFC_CASE(4096, 16, 16, 16)
+    FFC_CASE(8192, 32, 16, 16)
+    FFC_CASE(16384, 16, 32, 32)
+    FFC_CASE(32768, 32, 32, 32)
+  }
+#undef FFC_CASE
+  return -1;
+}
+template <class GEO, int DT> struct ConvRun { static void run(const ConvArgs& a) { sim_conv_t<GEO, DT>(a); } };
+
+}  // namespace ffc
+
+using namespace ffc;
+
+extern "C" {
+
+void ffcsim_set_tr(int on) { SimB::HAS_TR = on != 0; }
+
+// Plan introspection (also used by tests to build k_f in internal order on the host).
+int ffcsim_plan_info(int N, int dtype, int* nt, double* s_fwd, double* s_k, int32_t* kf_freq /* nt*1024 or null */) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  *nt = p.NT; *s_fwd = p.s_fwd; *s_k = p.s_k;
+  if (kf_freq) memcpy(kf_freq, p.kf_freq.data(), p.kf_freq.size() * 4);
+  return 0;
+}
+
+// Same contract as ffc_conv_fwd (include/flashfftconv_hip.h) but on host memory.
+int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
+                    void* y, int B, int H, int L, int conj_kf) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  if (L > N || (L & 3)) return -2;
+  ConvArgs a{};
+  a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
+  a.tab = p.blob.data(); a.t = p.tabs;
+  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
+  a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf;
+  return dispatch<ConvRun>(N, dtype, a);
+}
+
+}  // extern "C"

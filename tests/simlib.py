@@ -1,0 +1,78 @@
+"""ctypes access to the CPU wave simulator (libffcsim.so) + host-side helpers shared by tests."""
+import ctypes, os, subprocess, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "flash-fft-conv_amd")
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+DT_BF16, DT_F16 = 0, 1
+
+
+def build_sim(force=False):
+    so = os.path.join(LIBDIR, "libffcsim.so")
+    srcs = [os.path.join(CSRC, f) for f in ("ffc_sim.cpp", "ffc_plan.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("ffc_body.h", "ffc_modes.h", "ffc_layout.h", "ffc_plan.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        os.makedirs(LIBDIR, exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", so] + srcs)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build_sim())
+    return _lib
+
+
+def f32_to_bf16_bits(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def to_bits(x, dtype):
+    return f32_to_bf16_bits(x) if dtype == DT_BF16 else np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+
+
+def from_bits(b, dtype):
+    return bf16_bits_to_f32(b) if dtype == DT_BF16 else b.view(np.float16).astype(np.float32)
+
+
+def plan_info(N, dtype):
+    nt = ctypes.c_int(); sf = ctypes.c_double(); sk = ctypes.c_double()
+    rc = lib().ffcsim_plan_info(N, dtype, ctypes.byref(nt), ctypes.byref(sf), ctypes.byref(sk), None)
+    assert rc == 0, f"unsupported N={N}"
+    freq = np.zeros(nt.value * 1024, np.int32)
+    lib().ffcsim_plan_info(N, dtype, ctypes.byref(nt), ctypes.byref(sf), ctypes.byref(sk),
+                           freq.ctypes.data_as(ctypes.c_void_p))
+    return nt.value, sf.value, sk.value, freq
+
+
+def make_kf_internal(k, N, dtype):
+    """k (H, Lk) float -> internal-order k_f bits (H, NT*1024, 2), via float64 numpy FFT."""
+    nt, sf, sk, freq = plan_info(N, dtype)
+    kf = np.fft.fft(np.asarray(k, np.float64), n=N, axis=-1)[:, freq] * sk
+    out = np.stack([kf.real, kf.imag], -1).astype(np.float32)
+    return to_bits(out, dtype)
+
+
+def p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def sim_conv_fwd(N, dtype, u_bits, kf_bits, pre=None, post=None, conj=0):
+    B, H, L = u_bits.shape
+    y = np.zeros_like(u_bits)
+    rc = lib().ffcsim_conv_fwd(N, dtype, p(u_bits), p(kf_bits), p(pre), p(post), p(y), B, H, L, conj)
+    assert rc == 0, rc
+    return y
