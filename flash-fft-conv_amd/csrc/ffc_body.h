@@ -37,6 +37,7 @@ struct ConvArgs {
   int npair;             // ceil(B/2)
   int nchunk, ppc;       // chunks of pairs per head, pairs per chunk
   int conj_kf;           // 1: multiply by conj(k_f)  (input-gradient pass)
+  int fast;              // 1: L % 8 == 0 and 16-byte aligned tensors -> 16-byte global accesses
 };
 
 template <class B, class GEO, int DT>
@@ -79,7 +80,7 @@ struct Body {
   static FFC_FN void cmm(f32 (&ore)[16], f32 (&oim)[16], const Op& d, const Mat& F, int ms_lim = 2) {
 #pragma unroll
     for (int ms = 0; ms < 2; ms++) {
-      if (ms >= ms_lim) break;
+      if (ms >= ms_lim) continue;
       const u32(&fr)[4] = F.w[ms][0];
       const u32(&fi_re)[4] = F.w[ms][CONJ ? 1 : 2];  // multiplies data.im into re
       const u32(&fi_im)[4] = F.w[ms][CONJ ? 2 : 1];  // multiplies data.re into im
@@ -113,6 +114,14 @@ struct Body {
       im[r] = a * t.im[r] + b * t.re[r];
     }
   }
+  static FFC_FN void cmul_conj(f32 (&re)[16], f32 (&im)[16], const CT16& t) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      f32 a = re[r], b = im[r];
+      re[r] = a * t.re[r] + b * t.im[r];
+      im[r] = b * t.re[r] - a * t.im[r];
+    }
+  }
   // dtype pair (x) dtype pair, rounded back to dtype (the reference multiplies gates in the
   // activation dtype: kernels_bf16/monarch_cuda_32_32_32_kernel_bf16.h:409-429, 613-634).
   static FFC_FN u32 mul2(u32 a, u32 g) {
@@ -130,217 +139,313 @@ struct Body {
     }
   }
 
-  // ------------------------------------------------------------------ phase A (outer fwd)
-  static FFC_FN void phase_a(const ConvArgs& a, int h, int p, const Mat& F1, const CT16& base) {
-    const i32 lane = B::lane();
-    const int w = B::wave();
-    const i32 j = lane & 31, hi = lane >> 5;
-    const int b0 = 2 * p, b1 = 2 * p + 1;
-    const bool v1 = b1 < a.B;
-    const int64_t rowa = ((int64_t)b0 * a.H + h) * a.L, rowb = ((int64_t)(v1 ? b1 : b0) * a.H + h) * a.L;
-    const uint16_t* xa = (const uint16_t*)a.u + rowa;
-    const uint16_t* xb = (const uint16_t*)a.u + rowb;
-    const uint16_t* ga = a.pregate ? (const uint16_t*)a.pregate + rowa : nullptr;
-    const uint16_t* gb = a.pregate ? (const uint16_t*)a.pregate + rowb : nullptr;
-    int ms_lim = 2;
-    if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) ms_lim = 1;
-
-    U2 rawa[2][8], rawb[2][8];
+  // same with a runtime tile pair tp (x or y dword) and compile-time half th
+  static FFC_FN void xpose2(const U2 (&raw)[8], int tp, int th, u32 (&op)[4]) {
 #pragma unroll
-    for (int ms = 0; ms < 2; ms++) {
-      if (ms >= ms_lim) break;
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        i32 R = hi * 4 + (16 * ms + 8 * (e >> 2) + (e & 3));
-        i32 s1 = R / GEO::N1, n1 = R % GEO::N1;
-        i32 n = n1 * GEO::Mi + s1 * 128 + j * 4 + w * 128 * GEO::S1;
-        pred ok = n < a.L;
-        i32 o8 = n >> 2;
-        rawa[ms][e] = B::g_r64(xa, o8, ok);
-        rawb[ms][e] = B::g_r64(xb, o8, v1 ? ok : B::pfalse());
-        if (ga) {
-          U2 g = B::g_r64(ga, o8, ok);
-          rawa[ms][e].x = mul2(rawa[ms][e].x, g.x); rawa[ms][e].y = mul2(rawa[ms][e].y, g.y);
-          U2 g2 = B::g_r64(gb, o8, v1 ? ok : B::pfalse());
-          rawb[ms][e].x = mul2(rawb[ms][e].x, g2.x); rawb[ms][e].y = mul2(rawb[ms][e].y, g2.y);
-        }
-      }
-    }
-    u32 sre[16][2], sim[16][2];
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      Op op;
-#pragma unroll
-      for (int ms = 0; ms < 2; ms++) {
-        if (ms >= ms_lim) break;
-        xpose(rawa[ms], t, op.r[ms]);
-        xpose(rawb[ms], t, op.i[ms]);
-      }
-      f32 re[16], im[16];
-      zero(re); zero(im);
-      cmm<false, false>(re, im, op, F1, ms_lim);
-      if (t == 0) {
-        cmul(re, im, base);
-      } else {
-        CT16 c;
-        load_ct16(c, a.tab + a.t.ct + 8192 * t, lane);
-        cmul(c.re, c.im, base);
-        cmul(re, im, c);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
-        u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
-        if (t & 1) {
-          sre[r][t >> 1] = sre[r][t >> 1] | (vr << 16);
-          sim[r][t >> 1] = sim[r][t >> 1] | (vi << 16);
-        } else {
-          sre[r][t >> 1] = vr & 0xffffu;
-          sim[r][t >> 1] = vi & 0xffffu;
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      i32 R = hi * 4 + ((r & 3) + 8 * (r >> 2));
-      i32 s1 = R / GEO::N1, k1 = R % GEO::N1;
-      i32 m = s1 * 128 + j * 4 + w * 128 * GEO::S1;
-      i32 off = e_off<GEO, i32>(k1, m);
-      U2 vr; vr.x = sre[r][0]; vr.y = sre[r][1];
-      U2 vi; vi.x = sim[r][0]; vi.y = sim[r][1];
-      B::lds_w64(off, vr);
-      B::lds_w64(off + GEO::PLANE, vi);
+    for (int d = 0; d < 4; d++) {
+      u32 a = tp ? raw[2 * d].y : raw[2 * d].x;
+      u32 b = tp ? raw[2 * d + 1].y : raw[2 * d + 1].x;
+      op[d] = th ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
     }
   }
 
-  // ------------------------------------------------------------------ phase C (outer inverse)
-  static FFC_FN void phase_c(const ConvArgs& a, int h, int p, const Mat& F1) {
+  // ------------------------------------------------------------------ LDS-resident tables
+  static FFC_FN void copy_tab(const uint8_t* src, int lds_off, int bytes) {
+    const i32 tid = B::lane() + B::wave() * 64;
+    for (int i = 0; i < bytes / 16; i += GEO::WGW * 64) {
+      i32 idx = tid + i;
+      pred ok = idx < bytes / 16;
+      U4 v = B::g_r128p(src, idx, ok);
+      B::lds_w128(idx * 16 + lds_off, v, ok);
+    }
+  }
+  static FFC_FN void setup_tables(const uint8_t* tab, const PlanTabs& t) {
+    if constexpr (GEO::OUTER) {
+      copy_tab(tab + t.mat[0], GEO::L_F1, 6144);
+      copy_tab(tab + t.base, GEO::L_BASE, 8192);
+      copy_tab(tab + t.delta, GEO::L_DELTA, 256);
+      copy_tab(tab + t.omega, GEO::L_OMEGA, 256 * GEO::NW);
+    }
+    copy_tab(tab + t.mat[1], GEO::L_F2, 6144);
+    copy_tab(tab + t.twin, GEO::L_TW, 8192);
+    if constexpr (GEO::N3 != GEO::N2) copy_tab(tab + t.mat[2], GEO::L_F3, 6144);
+    if constexpr (GEO::TW2_SEP) copy_tab(tab + t.twin2, GEO::L_TW2, 8192);
+    B::barrier();
+  }
+  static FFC_FN void lds_mat(Mat& m, int off) {
     const i32 lane = B::lane();
-    const int w = B::wave();
-    const i32 j = lane & 31, hi = lane >> 5;
-    const int b0 = 2 * p, b1 = 2 * p + 1;
-    const bool v1 = b1 < a.B;
-    const int64_t rowa = ((int64_t)b0 * a.H + h) * a.L, rowb = ((int64_t)(v1 ? b1 : b0) * a.H + h) * a.L;
-    uint16_t* ya = (uint16_t*)a.y + rowa;
-    uint16_t* yb = (uint16_t*)a.y + rowb;
-    const uint16_t* ga = a.postgate ? (const uint16_t*)a.postgate + rowa : nullptr;
-    const uint16_t* gb = a.postgate ? (const uint16_t*)a.postgate + rowb : nullptr;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      U4 v = B::lds_r128(lane * 16 + (off + q * 1024));
+      m.w[q / 3][q % 3][0] = v.x; m.w[q / 3][q % 3][1] = v.y;
+      m.w[q / 3][q % 3][2] = v.z; m.w[q / 3][q % 3][3] = v.w;
+    }
+  }
+  static FFC_FN void lds_ct16(CT16& c, int off) {
+    const i32 lane = B::lane();
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+      U4 v = B::lds_r128(lane * 16 + (off + rr * 1024));
+      c.re[2 * rr] = B::as_f32(v.x); c.im[2 * rr] = B::as_f32(v.y);
+      c.re[2 * rr + 1] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
+    }
+  }
+  // t[r] *= tab[hi][r] where tab is a [2][16] complex f32 LDS table (lane-uniform per half-wave)
+  static FFC_FN void cmul_small(CT16& t, int off) {
+    const i32 hi = B::lane() >> 5;
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+      U4 v = B::lds_r128(hi * 128 + (off + rr * 16));
+      f32 br[2] = {B::as_f32(v.x), B::as_f32(v.z)}, bi[2] = {B::as_f32(v.y), B::as_f32(v.w)};
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        int r = 2 * rr + q;
+        f32 x = t.re[r], y = t.im[r];
+        t.re[r] = x * br[q] - y * bi[q];
+        t.im[r] = x * bi[q] + y * br[q];
+      }
+    }
+  }
 
+  struct Unit { int eb; int wq; };   // E base (bytes) of this wave's unit, wave index inside the unit
+
+  // ------------------------------------------------------------------ global <-> E row copies
+  // A unit's E holds ROWS rows of Mi points per plane.  OUTER: the rows are the n1 slices of one
+  // pair (plane 0 = batch row 2p, plane 1 = row 2p+1) and a wave moves only its own 128*S1-column
+  // slice (the columns it transforms in phases A/C, so no barrier is needed around the copies).
+  // Inner-only sizes: row g = pair q*G+g, the single wave of the unit moves the whole tile.
+  // 16-byte global accesses, 1 KiB contiguous per wave instruction when L % 8 == 0.
+  struct RowIO {
+    const uint16_t* src[2]; const uint16_t* gate[2]; uint16_t* dst[2]; bool valid[2];
+  };
+  static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, bool fast, bool rowok) {
+    if (fast) return B::g_r128p(base, n >> 3, (n < L) && rowok);
+    u32 w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      u32 lo = B::g_r16(base, n + 2 * q, ((n + 2 * q) < L) && rowok);
+      u32 hi = B::g_r16(base, n + (2 * q + 1), ((n + (2 * q + 1)) < L) && rowok);
+      w[q] = lo | (hi << 16);
+    }
+    U4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+  }
+  static FFC_FN void gstore8(uint16_t* base, i32 n, int L, bool fast, bool rowok, U4 v) {
+    if (fast) { B::g_w128(base, n >> 3, v, (n < L) && rowok); return; }
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      B::g_w16(base, n + 2 * q, w[q] & 0xffffu, ((n + 2 * q) < L) && rowok);
+      B::g_w16(base, n + (2 * q + 1), w[q] >> 16, ((n + (2 * q + 1)) < L) && rowok);
+    }
+  }
+  // LDS address of the 16-byte pair of chunks holding columns m..m+7 (m % 8 == 0) of `row`, and
+  // whether the two 8-byte halves are swapped by the bank swizzle.
+  static FFC_FN i32 pair_off(i32 row, i32 m, pred* swapped) {
+    i32 n2 = m / GEO::N3, n3 = m % GEO::N3;
+    i32 sig = (n2 / GEO::PER) % GEO::CR;
+    *swapped = (sig & 1) >= 1;
+    return row * (GEO::Mi * 2) + (n2 * GEO::CR + (((n3 >> 3) ^ (sig >> 1)) << 1)) * 8;
+  }
+  static constexpr int CPR = GEO::OUTER ? 16 * GEO::S1 : GEO::Mi / 8;   // 16-B chunks per row per wave
+  static constexpr int NCH = GEO::OUTER ? 8 : 2;                        // chunks per lane per plane
+
+  static FFC_FN void rows_in(const ConvArgs& a, int h, int pq, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    const bool fast = a.fast;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      pred sw;
+      i32 off = pair_off(row, m, &sw) + un.eb;
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        U4 v;
+        if constexpr (GEO::OUTER) {
+          const int b = 2 * pq + pl;
+          const bool ok = b < a.B;
+          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+          i32 n = row * GEO::Mi + m;
+          // rows entirely beyond L are never read (phase A substitutes zeros): skip them
+          v = gload8((const uint16_t*)a.u + ro, n, a.L, fast, ok);
+          if (a.pregate) {
+            U4 g = gload8((const uint16_t*)a.pregate + ro, n, a.L, fast, ok);
+            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
+          }
+        } else {
+          // row = pair index inside the tile; batch row differs per lane -> per-lane element offset
+          i32 b = (row + pq * GEO::G) * 2 + pl;
+          pred ok = b < a.B;
+          i32 n = m;
+          v = gload8_rows((const uint16_t*)a.u, b, h, a, n, fast, ok);
+          if (a.pregate) {
+            U4 g = gload8_rows((const uint16_t*)a.pregate, b, h, a, n, fast, ok);
+            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
+          }
+        }
+        U4 o;
+        o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
+        o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
+        B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+      }
+    }
+  }
+  // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
+  // 32 bits in 16-byte units (launcher checks the tensor size).
+  static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, bool fast, pred ok) {
+    if (fast) {
+      i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
+      return B::g_r128p(base, o16, ok && (n < a.L));
+    }
+    u32 w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      i32 e0 = (b * a.H + h) * a.L + n + 2 * q;
+      u32 lo = B::g_r16(base, e0, ok && ((n + 2 * q) < a.L));
+      u32 hi = B::g_r16(base, e0 + 1, ok && ((n + (2 * q + 1)) < a.L));
+      w[q] = lo | (hi << 16);
+    }
+    U4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+  }
+  static FFC_FN void gstore8_rows(uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, bool fast, pred ok, U4 v) {
+    if (fast) {
+      i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
+      B::g_w128(base, o16, v, ok && (n < a.L));
+      return;
+    }
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      i32 e0 = (b * a.H + h) * a.L + n + 2 * q;
+      B::g_w16(base, e0, w[q] & 0xffffu, ok && ((n + 2 * q) < a.L));
+      B::g_w16(base, e0 + 1, w[q] >> 16, ok && ((n + (2 * q + 1)) < a.L));
+    }
+  }
+
+  static FFC_FN void rows_out(const ConvArgs& a, int h, int pq, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    const bool fast = a.fast;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      pred sw;
+      i32 off = pair_off(row, m, &sw) + un.eb;
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        U4 o = B::lds_r128(off + pl * GEO::PLANE);
+        U4 v;
+        v.x = B::sel(sw, o.z, o.x); v.y = B::sel(sw, o.w, o.y);
+        v.z = B::sel(sw, o.x, o.z); v.w = B::sel(sw, o.y, o.w);
+        if constexpr (GEO::OUTER) {
+          const int b = 2 * pq + pl;
+          const bool ok = b < a.B;
+          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+          i32 n = row * GEO::Mi + m;
+          if (a.postgate) {
+            U4 g = gload8((const uint16_t*)a.postgate + ro, n, a.L, fast, ok);
+            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
+          }
+          gstore8((uint16_t*)a.y + ro, n, a.L, fast, ok, v);
+        } else {
+          i32 b = (row + pq * GEO::G) * 2 + pl;
+          pred ok = b < a.B;
+          if (a.postgate) {
+            U4 g = gload8_rows((const uint16_t*)a.postgate, b, h, a, m, fast, ok);
+            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
+          }
+          gstore8_rows((uint16_t*)a.y, b, h, a, m, fast, ok, v);
+        }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ phases A / C (outer DFT, in place)
+  // The wave owns columns [wq*128*S1, +128*S1) of every E row: 4 tiles t, lane j <-> column
+  // s1*128 + 4j + t.  FWD: rows are n1 (real pair x), result rows k1 with the W_N^{m k1} twiddle.
+  // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
+  // HALF: input rows n1 >= 16 are all zero (L <= 16*Mi, 32-point outer digit) -> one K-step.
+  template <bool FWD, bool HALF>
+  static FFC_FN void outer_stage(int L, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    const int w = un.wq;
+    const i32 j = lane & 31, hi = lane >> 5;
+    constexpr int ms_lim = (FWD && HALF) ? 1 : 2;
+    // tile-local row R = 4*hi + c (c a compile-time constant with bit 2 clear) -> column set
+    // s1 = c / N1 and E row rw = c % N1 + 4*hi.  e_off = row term + swizzled column term, so every
+    // access below is (one of S1 lane-dependent bases) + immediate.
+    i32 colb[GEO::S1];
+#pragma unroll
+    for (int s = 0; s < GEO::S1; s++)
+      colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
     U2 rawr[2][8], rawi[2][8];
 #pragma unroll
-    for (int ms = 0; ms < 2; ms++)
+    for (int ms = 0; ms < 2; ms++) {
+      if (ms >= ms_lim) continue;
 #pragma unroll
       for (int e = 0; e < 8; e++) {
-        i32 R = hi * 4 + (16 * ms + 8 * (e >> 2) + (e & 3));
-        i32 s1 = R / GEO::N1, k1 = R % GEO::N1;
-        i32 m = s1 * 128 + j * 4 + w * 128 * GEO::S1;
-        i32 off = e_off<GEO, i32>(k1, m);
-        rawr[ms][e] = B::lds_r64(off);
-        rawi[ms][e] = B::lds_r64(off + GEO::PLANE);
+        const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
+        const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+        i32 off = colb[s1] + rwc * (GEO::Mi * 2);
+        U2 vr = B::lds_r64(off), vi = B::lds_r64(off + GEO::PLANE);
+        if (FWD) {
+          pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
+          vr.x = B::sel(ok, vr.x, B::uconst(0)); vr.y = B::sel(ok, vr.y, B::uconst(0));
+          vi.x = B::sel(ok, vi.x, B::uconst(0)); vi.y = B::sel(ok, vi.y, B::uconst(0));
+        }
+        rawr[ms][e] = vr; rawi[ms][e] = vi;
       }
-    u32 sre[16][2], sim[16][2];
+    }
+    Mat F1;
+    lds_mat(F1, GEO::L_F1);
+    CT16 tw;
+    if (FWD) {
+      lds_ct16(tw, GEO::L_BASE);
+      cmul_small(tw, GEO::L_OMEGA + 256 * w);
+    }
+#pragma unroll 1
+    for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): kept a runtime loop to bound live ranges
+      u32 sre[16], sim[16];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      Op op;
+      for (int th = 0; th < 2; th++) {
+        Op op;
 #pragma unroll
-      for (int ms = 0; ms < 2; ms++) {
-        xpose(rawr[ms], t, op.r[ms]);
-        xpose(rawi[ms], t, op.i[ms]);
-      }
-      f32 re[16], im[16];
-      zero(re); zero(im);
-      cmm<true, false>(re, im, op, F1);
+        for (int ms = 0; ms < 2; ms++) {
+          if (ms >= ms_lim) continue;
+          xpose2(rawr[ms], tp, th, op.r[ms]);
+          xpose2(rawi[ms], tp, th, op.i[ms]);
+        }
+        f32 re[16], im[16];
+        zero(re); zero(im);
+        cmm<!FWD, false>(re, im, op, F1, ms_lim);
+        if (FWD) {
+          if (tp + th > 0) cmul_small(tw, GEO::L_DELTA);
+          cmul(re, im, tw);
+        }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
-        u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
-        if (t & 1) {
-          sre[r][t >> 1] = sre[r][t >> 1] | (vr << 16);
-          sim[r][t >> 1] = sim[r][t >> 1] | (vi << 16);
-        } else {
-          sre[r][t >> 1] = vr & 0xffffu;
-          sim[r][t >> 1] = vi & 0xffffu;
+        for (int r = 0; r < 16; r++) {
+          u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
+          u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
+          if (th == 1) {
+            const int c = (r & 3) + 8 * (r >> 2);
+            const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+            i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+            B::lds_w32(off, sre[r] | (vr << 16));
+            B::lds_w32(off + GEO::PLANE, sim[r] | (vi << 16));
+          } else {
+            sre[r] = vr & 0xffffu;
+            sim[r] = vi & 0xffffu;
+          }
         }
       }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      i32 R = hi * 4 + ((r & 3) + 8 * (r >> 2));
-      i32 s1 = R / GEO::N1, n1 = R % GEO::N1;
-      i32 n = n1 * GEO::Mi + s1 * 128 + j * 4 + w * 128 * GEO::S1;
-      pred ok = n < a.L;
-      i32 o8 = n >> 2;
-      U2 vr; vr.x = sre[r][0]; vr.y = sre[r][1];
-      U2 vi; vi.x = sim[r][0]; vi.y = sim[r][1];
-      if (ga) {
-        U2 g = B::g_r64(ga, o8, ok);
-        vr.x = mul2(vr.x, g.x); vr.y = mul2(vr.y, g.y);
-        U2 g2 = B::g_r64(gb, o8, v1 ? ok : B::pfalse());
-        vi.x = mul2(vi.x, g2.x); vi.y = mul2(vi.y, g2.y);
-      }
-      B::g_w64(ya, o8, vr, ok);
-      B::g_w64(yb, o8, vi, v1 ? ok : B::pfalse());
-    }
-  }
-
-  // ------------------------------------------------------------------ copy in / out (N <= 1024)
-  // Tile of G pairs (pairs q*G .. q*G+G-1 of head h); E row g = pair g, re = row 2p, im = row 2p+1.
-  static FFC_FN void copy_in(const ConvArgs& a, int h, int q) {
-    const i32 lane = B::lane();
-    const uint16_t* ub = (const uint16_t*)a.u + (int64_t)h * a.L;
-    const uint16_t* gbse = a.pregate ? (const uint16_t*)a.pregate + (int64_t)h * a.L : nullptr;
-    const int64_t bstride8 = ((int64_t)a.H * a.L) >> 2;   // 8-byte units per batch row
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      i32 ci = lane + i * 64;                 // chunk id within a plane (256 chunks of 4)
-      i32 g = ci / (GEO::Mi / 4), m = (ci % (GEO::Mi / 4)) * 4;
-      i32 pp = g + q * GEO::G;                // pair index
-      i32 bA = pp * 2, bB = pp * 2 + 1;
-      pred inl = m < a.L;
-      pred okA = inl && (bA < a.B), okB = inl && (bB < a.B);
-      i32 oA = bA * (int)bstride8 + (m >> 2), oB = bB * (int)bstride8 + (m >> 2);
-      U2 va = B::g_r64(ub, oA, okA), vb = B::g_r64(ub, oB, okB);
-      if (gbse) {
-        U2 g1 = B::g_r64(gbse, oA, okA), g2 = B::g_r64(gbse, oB, okB);
-        va.x = mul2(va.x, g1.x); va.y = mul2(va.y, g1.y);
-        vb.x = mul2(vb.x, g2.x); vb.y = mul2(vb.y, g2.y);
-      }
-      i32 off = e_off<GEO, i32>(g, m);
-      B::lds_w64(off, va);
-      B::lds_w64(off + GEO::PLANE, vb);
-    }
-  }
-  static FFC_FN void copy_out(const ConvArgs& a, int h, int q) {
-    const i32 lane = B::lane();
-    uint16_t* yb = (uint16_t*)a.y + (int64_t)h * a.L;
-    const uint16_t* gbse = a.postgate ? (const uint16_t*)a.postgate + (int64_t)h * a.L : nullptr;
-    const int64_t bstride8 = ((int64_t)a.H * a.L) >> 2;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      i32 ci = lane + i * 64;
-      i32 g = ci / (GEO::Mi / 4), m = (ci % (GEO::Mi / 4)) * 4;
-      i32 pp = g + q * GEO::G;
-      i32 bA = pp * 2, bB = pp * 2 + 1;
-      pred inl = m < a.L;
-      pred okA = inl && (bA < a.B), okB = inl && (bB < a.B);
-      i32 oA = bA * (int)bstride8 + (m >> 2), oB = bB * (int)bstride8 + (m >> 2);
-      i32 off = e_off<GEO, i32>(g, m);
-      U2 va = B::lds_r64(off), vb = B::lds_r64(off + GEO::PLANE);
-      if (gbse) {
-        U2 g1 = B::g_r64(gbse, oA, okA), g2 = B::g_r64(gbse, oB, okB);
-        va.x = mul2(va.x, g1.x); va.y = mul2(va.y, g1.y);
-        vb.x = mul2(vb.x, g2.x); vb.y = mul2(vb.y, g2.y);
-      }
-      B::g_w64(yb, oA, va, okA);
-      B::g_w64(yb, oB, vb, okB);
     }
   }
 
   // ------------------------------------------------------------------ phase B (inner tile)
-  struct InnerRegs { Mat F2, F3; CT16 tw, tw2; };
-
-  static FFC_FN void load_tile_op(int tau, Op& op) {
-    const i32 lane = B::lane();
+  static FFC_FN void load_tile_op(int tau, Op& op, Unit un) {
+    const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const i32 sV = c / GEO::N3;
     if (B::HAS_TR) {
@@ -354,7 +459,7 @@ struct Body {
           i32 sU = U / GEO::N2, n2 = U % GEO::N2;
           i32 row = sU * GEO::SV + ((g16 * 16) / GEO::N3) + tau * GEO::G;
           i32 m = n2 * GEO::N3 + n3b + (i16 & 3) * 4;
-          i32 off = e_off<GEO, i32>(row, m);
+          i32 off = e_off<GEO, i32>(row, m) + un.eb;
           U2 vr = B::lds_r64_tr(off), vi = B::lds_r64_tr(off + GEO::PLANE);
           op.r[ms][2 * rho] = vr.x; op.r[ms][2 * rho + 1] = vr.y;
           op.i[ms][2 * rho] = vi.x; op.i[ms][2 * rho + 1] = vi.y;
@@ -372,7 +477,7 @@ struct Body {
             i32 U = hi * 4 + (16 * ms + 8 * (e >> 2) + (e & 3));
             i32 sU = U / GEO::N2, n2 = U % GEO::N2;
             i32 row = sU * GEO::SV + sV + tau * GEO::G;
-            i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3);
+            i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3) + un.eb;
             wr[hf] = B::lds_r16(off);
             wi[hf] = B::lds_r16(off + GEO::PLANE);
           }
@@ -382,11 +487,17 @@ struct Body {
     }
   }
 
-  static FFC_FN void inner_tile(const ConvArgs& a, int h, int tau, const InnerRegs& R) {
+  struct InnerRegs { Mat F2; CT16 tw; };
+  static FFC_FN void load_inner(InnerRegs& R) {
+    lds_mat(R.F2, GEO::L_F2);
+    lds_ct16(R.tw, GEO::L_TW);
+  }
+
+  static FFC_FN void inner_tile(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
     const i32 lane = B::lane();
     const i32 c = lane & 31, hi = lane >> 5;
     Op op;
-    load_tile_op(tau, op);
+    load_tile_op(tau, op, un);
     f32 re[16], im[16];
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     zero(re); zero(im);
@@ -395,7 +506,13 @@ struct Body {
     to_op(re, im, op);
     // stage b: contract n3 (B-form) -> [V'=(sV,k3) regs][U' lanes]
     zero(re); zero(im);
-    cmm<false, false>(re, im, op, R.F3);
+    if constexpr (GEO::N3 != GEO::N2) {
+      Mat F3;
+      lds_mat(F3, GEO::L_F3);
+      cmm<false, false>(re, im, op, F3);
+    } else {
+      cmm<false, false>(re, im, op, R.F2);
+    }
     // (x) k_f
     {
       const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
@@ -418,8 +535,20 @@ struct Body {
     to_op(re, im, op);
     // inverse stage b: contract k3 (A-form, conj) -> [U' regs][V''=(sV,n3) lanes]
     zero(re); zero(im);
-    cmm<true, true>(re, im, op, R.F3);
-    cmul(re, im, R.tw2);
+    if constexpr (GEO::N3 != GEO::N2) {
+      Mat F3;
+      lds_mat(F3, GEO::L_F3);
+      cmm<true, true>(re, im, op, F3);
+    } else {
+      cmm<true, true>(re, im, op, R.F2);
+    }
+    if constexpr (GEO::TW2_SEP) {
+      CT16 tw2;
+      lds_ct16(tw2, GEO::L_TW2);
+      cmul(re, im, tw2);
+    } else {
+      cmul_conj(re, im, R.tw);
+    }
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]
     zero(re); zero(im);
@@ -458,7 +587,7 @@ struct Body {
       i32 sV = V / GEO::N3, n3 = V % GEO::N3;
       i32 sU = c / GEO::N2, n2 = c % GEO::N2;
       i32 row = sU * GEO::SV + sV + tau * GEO::G;
-      i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3);
+      i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3) + un.eb;
       U2 vr, vi;
       vr.x = B::template pack<DT>(re[4 * rq], re[4 * rq + 1]);
       vr.y = B::template pack<DT>(re[4 * rq + 2], re[4 * rq + 3]);
@@ -470,41 +599,60 @@ struct Body {
   }
 
   // ------------------------------------------------------------------ workgroup entry: conv
-  // Workgroup wg handles head h and one chunk of that head's pairs.
+  // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
-    const i32 lane = B::lane();
-    InnerRegs R;
-    load_mat(R.F2, a.tab + a.t.mat[1], lane);
-    if (GEO::N3 != GEO::N2) load_mat(R.F3, a.tab + a.t.mat[2], lane); else R.F3 = R.F2;
-    load_ct16(R.tw, a.tab + a.t.twin, lane);
-    load_ct16(R.tw2, a.tab + a.t.twin2, lane);
+    setup_tables(a.tab, a.t);
+    const int wv = B::wave();
+    Unit un;
+    un.wq = wv % GEO::NW;
+    const int u = wv / GEO::NW;
+    un.eb = u * GEO::EBYTES;
     const int p0 = chunk * a.ppc;
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      const int w = B::wave();
-      Mat F1;
-      CT16 base;
-      load_mat(F1, a.tab + a.t.mat[0], lane);
-      load_ct16(base, a.tab + a.t.base + 8192 * w, lane);
-      for (int p = p0; p < p1; p++) {
-        phase_a(a, h, p, F1, base);
+      const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int p = p0 + it * GEO::UPW + u;
+        const bool act = p < p1;
+        if (act) {
+          rows_in(a, h, p, un);
+          B::lds_fence();
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) outer_stage<true, true>(a.L, un);
+          else outer_stage<true, false>(a.L, un);
+        }
         B::barrier();
-        for (int tt = 0; tt < GEO::TPW; tt++) inner_tile(a, h, w * GEO::TPW + tt, R);
+        if (act) {
+          InnerRegs R;
+          load_inner(R);
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt++) inner_tile(a, h, un.wq * GEO::TPW + tt, R, un);
+        }
         B::barrier();
-        phase_c(a, h, p, F1);
-        B::barrier();
+        if (act) {
+          outer_stage<false, false>(a.L, un);
+          B::lds_fence();
+          rows_out(a, h, p, un);
+        }
       }
     } else {
-      // tiles of G pairs
+      // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
-      for (int q = q0; q < q1; q++) {
-        copy_in(a, h, q);
-        B::barrier();
-        inner_tile(a, h, 0, R);
-        B::barrier();
-        copy_out(a, h, q);
-        B::barrier();
+      const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
+      InnerRegs R;
+      load_inner(R);
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int q = q0 + it * GEO::UPW + u;
+        const bool act = q < q1;
+        if (act) {
+          rows_in(a, h, q, un);
+          B::lds_fence();
+          inner_tile(a, h, 0, R, un);
+          B::lds_fence();
+          rows_out(a, h, q, un);
+        }
       }
     }
   }

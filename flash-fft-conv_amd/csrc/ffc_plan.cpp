@@ -172,22 +172,29 @@ void build(HostPlan* p) {
     int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
     cis((double)(n3 * k2), GEO::Mi, 1.0, re, im);
   });
-  t.base = bl.alloc(8192 * GEO::NW);
-  t.ct = bl.alloc(8192 * 4);
+  t.base = bl.alloc(8192);
+  t.delta = bl.alloc(256);
+  t.omega = bl.alloc(256 * GEO::NW);
   t.oi_a = bl.alloc(GEO::NT * 32 * GEO::SV * 8);
   t.oi_b = bl.alloc(GEO::NT * GEO::SU * 2 * 16 * 8);
   if (GEO::OUTER) {
-    for (int w = 0; w < GEO::NW; w++)
-      fill_ctab16(p->blob.data() + t.base + 8192 * w, [&](int lane, int r, double* re, double* im) {
-        int R = acc_row(r, lane >> 5), s1 = R / GEO::N1, k1 = R % GEO::N1, j = lane & 31;
-        int m = w * 128 * GEO::S1 + s1 * 128 + 4 * j;
-        cis(-(double)m * k1, N, p->s_fwd, re, im);
-      });
-    for (int tt = 0; tt < 4; tt++)
-      fill_ctab16(p->blob.data() + t.ct + 8192 * tt, [&](int lane, int r, double* re, double* im) {
-        int k1 = acc_row(r, lane >> 5) % GEO::N1;
-        cis(-(double)tt * k1, N, 1.0, re, im);
-      });
+    fill_ctab16(p->blob.data() + t.base, [&](int lane, int r, double* re, double* im) {
+      int R = acc_row(r, lane >> 5), s1 = R / GEO::N1, k1 = R % GEO::N1, j = lane & 31;
+      cis(-(double)(s1 * 128 + 4 * j) * k1, N, p->s_fwd, re, im);
+    });
+    float* dl = (float*)(p->blob.data() + t.delta);
+    float* om = (float*)(p->blob.data() + t.omega);
+    for (int hi = 0; hi < 2; hi++)
+      for (int r = 0; r < 16; r++) {
+        int k1 = acc_row(r, hi) % GEO::N1;
+        double re, im;
+        cis(-(double)k1, N, 1.0, &re, &im);
+        dl[(hi * 16 + r) * 2] = (float)re; dl[(hi * 16 + r) * 2 + 1] = (float)im;
+        for (int w = 0; w < GEO::NW; w++) {
+          cis(-(double)(128 * GEO::S1 * w) * k1, N, 1.0, &re, &im);
+          om[((w * 2 + hi) * 16 + r) * 2] = (float)re; om[((w * 2 + hi) * 16 + r) * 2 + 1] = (float)im;
+        }
+      }
     float* a = (float*)(p->blob.data() + t.oi_a);
     float* bb = (float*)(p->blob.data() + t.oi_b);
     for (int tau = 0; tau < GEO::NT; tau++) {

@@ -10,8 +10,9 @@ namespace ffc {
 struct PlanTabs {      // byte offsets into the plan blob
   int mat[3];          // operand tables of digits N1,N2,N3: [6][64][4] u32
   int twin, twin2;     // inner twiddle, fwd / inverse (ctab16)
-  int base;            // [NW] ctab16 : outer fwd twiddle at tile t=0 (carries s_fwd)
-  int ct;              // [4]  ctab16 : W_N^{t*k1}
+  int base;            // ctab16 : s_fwd * W_N^{(s1*128 + 4j)*k1}  (outer fwd twiddle of wave 0, tile 0)
+  int delta;           // [2 hi][16 r] complex f32 : W_N^{k1}            (tile -> tile+1 step)
+  int omega;           // [NW][2][16] complex f32 : W_N^{128*S1*w*k1}    (wave offset)
   int oi_a;            // [NT][32][SV] complex f32 : W_N^{-n2*N3*k1}
   int oi_b;            // [NT][SU][2][16] complex f32 : W_N^{-n3*k1}
   int total;

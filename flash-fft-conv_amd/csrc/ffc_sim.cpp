@@ -84,6 +84,17 @@ struct SimB {
   static void lds_w64(const i32& off, const U2& v) {
     for (int i = 0; i < 64; i++) { chk(off.v[i], 8); memcpy(L() + off.v[i], &v.x.v[i], 4); memcpy(L() + off.v[i] + 4, &v.y.v[i], 4); }
   }
+  static void lds_w32(const i32& off, const u32& v) {
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 4); memcpy(L() + off.v[i], &v.v[i], 4); }
+  }
+  static void lds_w128(const i32& off, const U4& v, const pred& p) {
+    for (int i = 0; i < 64; i++)
+      if (p.v[i]) {
+        chk(off.v[i], 16);
+        memcpy(L() + off.v[i], &v.x.v[i], 4); memcpy(L() + off.v[i] + 4, &v.y.v[i], 4);
+        memcpy(L() + off.v[i] + 8, &v.z.v[i], 4); memcpy(L() + off.v[i] + 12, &v.w.v[i], 4);
+      }
+  }
   static U4 lds_r128(const i32& off) {
     U4 r;
     for (int i = 0; i < 64; i++) {
@@ -113,6 +124,18 @@ struct SimB {
       }
     }
     return r;
+  }
+  static void lds_fence() {}
+  static i32 opaque(const i32& x) { return x; }
+  static u32 uconst(uint32_t c) { return u32(c); }
+  static u32 sel(const pred& p, const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] ? a.v[i] : b.v[i]; return r; }
+  static u32 g_r16(const void* base, const i32& e, const pred& p) {
+    u32 r;
+    for (int i = 0; i < 64; i++) { uint16_t h = 0; if (p.v[i]) memcpy(&h, (const uint8_t*)base + (int64_t)e.v[i] * 2, 2); r.v[i] = h; }
+    return r;
+  }
+  static void g_w16(void* base, const i32& e, const u32& v, const pred& p) {
+    for (int i = 0; i < 64; i++) if (p.v[i]) { uint16_t h = (uint16_t)v.v[i]; memcpy((uint8_t*)base + (int64_t)e.v[i] * 2, &h, 2); }
   }
   static U2 g_r64(const void* base, const i32& o8, const pred& p) {
     U2 r;
@@ -180,6 +203,7 @@ struct SimB {
   template <int DT> static f32 unpack_hi(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)(a.v[i] >> 16)); return r; }
 };
 bool SimB::HAS_TR = true;
+static bool g_force_slow = false;
 
 // Run `fn(wg_index)` for one workgroup of nwaves wavefronts with lds_bytes of LDS.
 template <class F>
@@ -199,7 +223,7 @@ template <class GEO, int DT>
 static void sim_conv_t(const ConvArgs& a) {
   for (int h = 0; h < a.H; h++)
     for (int c = 0; c < a.nchunk; c++)
-      run_wg(GEO::NW, GEO::EBYTES, [&]() { Body<SimB, GEO, DT>::conv(a, h, c); });
+      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Body<SimB, GEO, DT>::conv(a, h, c); });
 }
 
 template <template <class, int> class FN, class... A>
@@ -230,6 +254,35 @@ using namespace ffc;
 extern "C" {
 
 void ffcsim_set_tr(int on) { SimB::HAS_TR = on != 0; }
+void ffcsim_force_slow_io(int on) { g_force_slow = on != 0; }
+
+// Mirror of ffc_selftest_primitives (ffc_hip.hip selftest_kernel) on the simulator backend.
+int ffcsim_selftest_primitives(const uint32_t* in, uint32_t* out) {
+  run_wg(1, 1024, [&]() {
+    using Bk = SimB;
+    Bk::u32 a[4], b[4];
+    for (int i = 0; i < 4; i++) for (int l = 0; l < 64; l++) { a[i].v[l] = in[l * 8 + i]; b[i].v[l] = in[l * 8 + 4 + i]; }
+    Bk::f32 acc[16], acc2[16];
+    for (int i = 0; i < 16; i++) { acc[i] = Bk::f32(0.f); acc2[i] = Bk::f32(0.f); }
+    Bk::mfma<DT_BF16>(acc, a, b);
+    Bk::mfma<DT_F16>(acc2, a, b);
+    Bk::i32 lane = Bk::lane();
+    Bk::U2 w; w.x = a[0]; w.y = a[1];
+    Bk::lds_w64(lane * 8, w);
+    Bk::U2 t = Bk::lds_r64_tr(((lane * 5 + 3) & 63) * 8);
+    Bk::u32 p0 = Bk::pack<DT_BF16>(acc[0], acc[1]), p1 = Bk::pack<DT_F16>(acc[0], acc[1]);
+    Bk::f32 u0 = Bk::unpack_lo<DT_F16>(a[2]), u1 = Bk::unpack_hi<DT_F16>(a[2]);
+    Bk::f32 u2 = Bk::unpack_lo<DT_BF16>(a[2]), u3 = Bk::unpack_hi<DT_BF16>(a[2]);
+    for (int l = 0; l < 64; l++) {
+      for (int i = 0; i < 16; i++) { memcpy(&out[l * 40 + i], &acc[i].v[l], 4); memcpy(&out[l * 40 + 16 + i], &acc2[i].v[l], 4); }
+      out[l * 40 + 32] = t.x.v[l]; out[l * 40 + 33] = t.y.v[l];
+      out[l * 40 + 34] = p0.v[l]; out[l * 40 + 35] = p1.v[l];
+      memcpy(&out[l * 40 + 36], &u0.v[l], 4); memcpy(&out[l * 40 + 37], &u1.v[l], 4);
+      memcpy(&out[l * 40 + 38], &u2.v[l], 4); memcpy(&out[l * 40 + 39], &u3.v[l], 4);
+    }
+  });
+  return 0;
+}
 
 // Plan introspection (also used by tests to build k_f in internal order on the host).
 int ffcsim_plan_info(int N, int dtype, int* nt, double* s_fwd, double* s_k, int32_t* kf_freq /* nt*1024 or null */) {
@@ -245,12 +298,13 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
                     void* y, int B, int H, int L, int conj_kf) {
   HostPlan p;
   if (!build_plan(N, dtype, &p)) return -1;
-  if (L > N || (L & 3)) return -2;
+  if (L > N || L <= 0) return -2;
   ConvArgs a{};
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
   a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
   a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf;
+  a.fast = (L % 8 == 0) && !g_force_slow;
   return dispatch<ConvRun>(N, dtype, a);
 }
 

@@ -1,0 +1,7 @@
+"""MI355X-native FlashFFTConv.  Same public surface as the reference package
+(/root/reference/flashfftconv/__init__.py:1-2)."""
+from .conv import FlashFFTConv
+from .depthwise_1d import FlashDepthWiseConv1d
+
+FlashDepthwiseConv1d = FlashDepthWiseConv1d  # README spelling of the reference
+__all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d"]

@@ -1,0 +1,52 @@
+"""ctypes binding of libflashfftconv_hip.so (C-ABI in include/flashfftconv_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised (the reference raises RuntimeError from TORCH_CHECK the same way,
+csrc/flashfftconv/monarch_cuda/monarch_fwd.h:196-528)."""
+import ctypes, os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libflashfftconv_hip.so")
+_lib = None
+
+c_vp, c_i64, c_int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"flashfftconv: HIP library not built ({LIB_PATH}); run `python flash-fft-conv_amd/build.py`")
+        L = ctypes.CDLL(LIB_PATH)
+        L.ffc_last_error.restype = ctypes.c_char_p
+        L.ffc_plan_create.argtypes = [c_i64, c_int, ctypes.POINTER(c_vp)]
+        L.ffc_plan_destroy.argtypes = [c_vp]
+        L.ffc_plan_kf_elems.argtypes = [c_vp]; L.ffc_plan_kf_elems.restype = c_i64
+        L.ffc_plan_kf_scale.argtypes = [c_vp]; L.ffc_plan_kf_scale.restype = ctypes.c_double
+        L.ffc_plan_kf_index.argtypes = [c_vp, c_vp]
+        L.ffc_kernel_fft.argtypes = [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]
+        L.ffc_kf_pack.argtypes = [c_vp, c_vp, c_i64, c_vp, c_vp]
+        L.ffc_conv_fwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
+        L.ffc_dkf_workspace_bytes.argtypes = [c_vp, c_i64, c_i64]; L.ffc_dkf_workspace_bytes.restype = c_i64
+        L.ffc_conv_bwd_dkf.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
+        L.ffc_kernel_ifft_grad.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]
+        L.ffc_conv1d_fwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]
+        L.ffc_conv1d_bwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]
+        L.ffc_selftest_primitives.argtypes = [c_vp, c_vp]
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"flashfftconv: {what} failed: {lib().ffc_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,145 @@
+"""FlashFFTConv module + autograd for MI355X (drop-in for reference flashfftconv/conv.py).
+
+    conv = FlashFFTConv(seqlen, dtype=torch.bfloat16).to(device)
+    y = conv(u, k)                        # u (B,H,L) bf16/fp16, k (H,Lk) fp32  ->  (B,H,L)
+    y = conv(u, k, pregate, postgate)     # y = postgate * conv(u * pregate, k)
+
+Semantics: y = iFFT(FFT(u, N) * FFT(k, N)).real[..., :L] with N = seqlen (reference
+tests/test_flashfftconv.py:5-13).  The reference's 4.9 KLoC `if seqlen == ...` dispatch
+(conv.py:563-4958) collapses to one table-driven plan inside the HIP library."""
+import ctypes
+import torch
+
+from . import _lib
+
+_DT = {torch.bfloat16: 0, torch.float16: 1}
+SUPPORTED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
+
+
+class _Plan:
+    """Owns an ffc_plan (DFT tiles + twiddles on the device) for one (fft size, dtype, device)."""
+
+    def __init__(self, seqlen, dtype, device):
+        self.handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().ffc_plan_create(seqlen, _DT[dtype], ctypes.byref(self.handle)), "ffc_plan_create")
+        self.kf_elems = _lib.lib().ffc_plan_kf_elems(self.handle)
+        self.seqlen, self.dtype, self.device = seqlen, dtype, device
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().ffc_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def _conv(plan, u, kf, pregate, postgate, conj):
+    B, H, L = u.shape
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().ffc_conv_fwd(plan.handle, _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
+                                       _lib.ptr(y), B, H, L, int(conj), _lib.stream_ptr()), "ffc_conv_fwd")
+    return y
+
+
+def _kernel_fft(plan, k):
+    """k (H, Lk) fp32 -> k_f in the plan's internal order (H, kf_elems, 2), plan dtype."""
+    H = k.shape[0]
+    kf = torch.empty(H, plan.kf_elems, 2, dtype=plan.dtype, device=k.device)
+    k32 = k.detach().to(torch.float32).contiguous()
+    _lib.check(_lib.lib().ffc_kernel_fft(plan.handle, _lib.ptr(k32), H, k32.shape[-1], _lib.ptr(kf), _lib.stream_ptr()),
+               "ffc_kernel_fft")
+    return kf
+
+
+def _check_inputs(mod, u, k, gates):
+    if not u.is_cuda:
+        raise RuntimeError("FlashFFTConv: u must be a CUDA/HIP tensor (no CPU fallback in the product path)")
+    if u.dim() != 3:
+        raise RuntimeError("FlashFFTConv: u must be (B, H, L)")
+    if u.dtype != mod.dtype:
+        raise RuntimeError(f"FlashFFTConv: u.dtype {u.dtype} != module dtype {mod.dtype}")
+    B, H, L = u.shape
+    if L > mod.seqlen:
+        raise RuntimeError(f"FlashFFTConv: L={L} exceeds fft size {mod.seqlen}")
+    if k.dim() != 2 or k.shape[0] != H or k.shape[-1] > mod.seqlen:
+        raise RuntimeError("FlashFFTConv: k must be (H, Lk) with Lk <= fft size")
+    for g in gates:
+        if g is not None and (g.shape != u.shape or g.dtype != u.dtype):
+            raise RuntimeError("FlashFFTConv: gates must match u in shape and dtype")
+
+
+class _FlashFFTConvFn(torch.autograd.Function):
+    # reference: FlashFFTConvFunc (conv.py:563) and GatedFlashFFTConvFunc (conv.py:3236)
+
+    @staticmethod
+    def forward(ctx, u, k, mod, pregate, postgate):
+        _check_inputs(mod, u, k, (pregate, postgate))
+        plan = mod._get_plan(u.device)
+        u = u.contiguous()
+        pregate = None if pregate is None else pregate.contiguous()
+        postgate = None if postgate is None else postgate.contiguous()
+        kf = _kernel_fft(plan, k)
+        ctx.plan, ctx.k_len, ctx.k_dtype, ctx.gated = plan, k.shape[-1], k.dtype, pregate is not None
+        if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
+            if ctx.gated:
+                ctx.save_for_backward(u, kf, pregate, postgate)
+            else:
+                ctx.save_for_backward(u, kf)
+        return _conv(plan, u, kf, pregate, postgate, False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.saved_tensors:
+            raise RuntimeError("FlashFFTConv: backward needs module.training=True at forward time")
+        plan = ctx.plan
+        dout = dout.contiguous()
+        if ctx.gated:
+            u, kf, pregate, postgate = ctx.saved_tensors
+        else:
+            (u, kf), pregate, postgate = ctx.saved_tensors, None, None
+        B, H, L = u.shape
+        lib = _lib.lib()
+        # dk: fp32 accumulation of FFT(dout*postgate) * conj(FFT(u*pregate)) over the batch, then inverse
+        ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
+        _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(pregate), _lib.ptr(postgate),
+                                        _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_dkf")
+        dk = torch.empty(H, ctx.k_len, dtype=torch.float32, device=u.device)
+        _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, ctx.k_len, _lib.ptr(dk), _lib.stream_ptr()),
+                   "ffc_kernel_ifft_grad")
+        dk = dk.to(ctx.k_dtype)
+        if not ctx.gated:
+            du = _conv(plan, dout, kf, None, None, True)
+            return du, dk, None, None, None
+        # gated: dv = corr(dout*postgate, k); du = dv*pregate; dpregate = dv*u; dpostgate = dout*conv(u*pregate)
+        du = _conv(plan, dout, kf, postgate, pregate, True)
+        dpre = _conv(plan, dout, kf, postgate, u, True)
+        dpost = _conv(plan, u, kf, pregate, dout, False)
+        return du, dk, None, dpre, dpost
+
+
+class FlashFFTConv(torch.nn.Module):
+    """reference: flashfftconv/conv.py:71-560."""
+
+    def __init__(self, seqlen, dtype=torch.float16, use_32_butterfly=True):
+        super().__init__()
+        assert dtype == torch.bfloat16 or dtype == torch.float16
+        if seqlen not in SUPPORTED_SEQLENS:
+            raise NotImplementedError(f"seqlen {seqlen} not supported")
+        self.seqlen = seqlen
+        self.dtype = dtype
+        self.use_32_butterfly = use_32_butterfly
+        self._plans = {}
+
+    def _get_plan(self, device):
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        p = self._plans.get(key)
+        if p is None:
+            p = _Plan(self.seqlen, self.dtype, device)
+            self._plans[key] = p
+        return p
+
+    def forward(self, u, k, pregate=None, postgate=None):
+        if pregate is not None or postgate is not None:
+            assert pregate is not None and postgate is not None
+        return _FlashFFTConvFn.apply(u, k, self, pregate, postgate)

@@ -41,10 +41,11 @@ def bf16_bits_to_f32(b):
 
 
 def to_bits(x, dtype):
-    return f32_to_bf16_bits(x) if dtype == DT_BF16 else np.asarray(x, np.float32).astype(np.float16).view(np.uint16)
+    return f32_to_bf16_bits(x) if dtype == DT_BF16 else np.ascontiguousarray(np.asarray(x, np.float32).astype(np.float16)).view(np.uint16)
 
 
 def from_bits(b, dtype):
+    b = np.ascontiguousarray(b)
     return bf16_bits_to_f32(b) if dtype == DT_BF16 else b.view(np.float16).astype(np.float32)
 
 
