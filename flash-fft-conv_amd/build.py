@@ -6,7 +6,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 HIP_SO = os.path.join(LIB, "libflashfftconv_hip.so")
 SIM_SO = os.path.join(LIB, "libffcsim.so")
-HIP_SRCS = ["ffc_hip.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
+HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
 
@@ -19,14 +19,31 @@ def _stale(target, srcs):
 
 
 def build_hip(force=False, verbose=False):
+    """Compile every translation unit for gfx950 in parallel, then link the shared library."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in HIP_SRCS if os.path.exists(os.path.join(CSRC, f))]
-    if force or _stale(HIP_SO, srcs):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", HIP_SO] + srcs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    obj_dir = os.path.join(LIB, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "flashfftconv_hip.h")))
+
+    def compile_one(f):
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(obj_dir, f + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
+        res = list(ex.map(compile_one, HIP_SRCS))
+    objs = [o for o, _ in res]
+    if force or any(ch for _, ch in res) or not os.path.exists(HIP_SO):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
     return HIP_SO
 
 

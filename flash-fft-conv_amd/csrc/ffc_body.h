@@ -493,12 +493,10 @@ struct Body {
     lds_ct16(R.tw, GEO::L_TW);
   }
 
-  static FFC_FN void inner_tile(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
-    const i32 lane = B::lane();
-    const i32 c = lane & 31, hi = lane >> 5;
+  // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
+  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, f32 (&re)[16], f32 (&im)[16]) {
     Op op;
     load_tile_op(tau, op, un);
-    f32 re[16], im[16];
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     zero(re); zero(im);
     cmm<false, true>(re, im, op, R.F2);
@@ -513,25 +511,13 @@ struct Body {
     } else {
       cmm<false, false>(re, im, op, R.F2);
     }
-    // (x) k_f
-    {
-      const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
-#pragma unroll
-      for (int rq = 0; rq < 4; rq++) {
-        i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c);
-        U4 v = B::g_r128(kfh, idx);
-        u32 wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
-          if (a.conj_kf) ki = B::fconst(0.f) - ki;
-          int r = 4 * rq + q;
-          f32 x = re[r], y = im[r];
-          re[r] = x * kr - y * ki;
-          im[r] = x * ki + y * kr;
-        }
-      }
-    }
+  }
+  // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
+  static FFC_FN void tile_inv(const uint8_t* tab, const PlanTabs& t, int tau, const InnerRegs& R, Unit un,
+                              f32 (&re)[16], f32 (&im)[16]) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    Op op;
     to_op(re, im, op);
     // inverse stage b: contract k3 (A-form, conj) -> [U' regs][V''=(sV,n3) lanes]
     zero(re); zero(im);
@@ -555,8 +541,8 @@ struct Body {
     cmm<true, true>(re, im, op, R.F2);
     // outer inverse twiddle W_N^{-(n2*N3+n3)*k1}
     if constexpr (GEO::OUTER) {
-      const uint8_t* pa = a.tab + a.t.oi_a + (int64_t)tau * (32 * GEO::SV * 8);
-      const uint8_t* pb = a.tab + a.t.oi_b + (int64_t)tau * (GEO::SU * 2 * 16 * 8);
+      const uint8_t* pa = tab + t.oi_a + (int64_t)tau * (32 * GEO::SV * 8);
+      const uint8_t* pb = tab + t.oi_b + (int64_t)tau * (GEO::SU * 2 * 16 * 8);
       f32 are[GEO::SV], aim[GEO::SV];
 #pragma unroll
       for (int s = 0; s < GEO::SV; s++) {
@@ -596,6 +582,33 @@ struct Body {
       B::lds_w64(off, vr);
       B::lds_w64(off + GEO::PLANE, vi);
     }
+  }
+
+  static FFC_FN void inner_tile(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    f32 re[16], im[16];
+    tile_fwd(tau, R, un, re, im);
+    // (x) k_f
+    {
+      const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c);
+        U4 v = B::g_r128(kfh, idx);
+        u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
+          if (a.conj_kf) ki = B::fconst(0.f) - ki;
+          int r = 4 * rq + q;
+          f32 x = re[r], y = im[r];
+          re[r] = x * kr - y * ki;
+          im[r] = x * ki + y * kr;
+        }
+      }
+    }
+    tile_inv(a.tab, a.t, tau, R, un, re, im);
   }
 
   // ------------------------------------------------------------------ workgroup entry: conv

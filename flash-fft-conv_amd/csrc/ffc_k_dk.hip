@@ -1,0 +1,32 @@
+// dk_f -> dk kernel (Modes::dkifft) + ffc_kernel_ifft_grad.
+#include "ffc_dev.h"
+using namespace ffc;
+
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void dkifft_kernel(DkArgs a) {
+  Modes<DevB, GEO, DT>::dkifft(a, blockIdx.x);
+}
+template <class GEO, int DT>
+struct DkLaunch {
+  static int run(const DkArgs& a, hipStream_t st) {
+    static int rc = ffc_set_lds(dkifft_kernel<GEO, DT>, GEO::LDS_BYTES);
+    if (rc) return rc;
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    hipLaunchKernelGGL((dkifft_kernel<GEO, DT>), dim3((nunits + GEO::UPW - 1) / GEO::UPW), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffc_fail(std::string("dkifft_kernel launch: ") + hipGetErrorString(e));
+  }
+};
+
+extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream) {
+  if (!p || !ws || !dk) return ffc_fail("null arg");
+  if (H <= 0 || Lk <= 0 || Lk > p->hp.N) return ffc_fail("dk must be (H, Lk) with 0 < Lk <= fft_size");
+  int nchunk, ppc;
+  ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
+  DkArgs a{};
+  a.ws = (const float*)ws; a.dk = dk; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = (int)Lk;
+  a.nslab = nchunk * (8 / p->hp.NW);
+  a.scale = (float)(1.0 / ((double)p->hp.N * p->hp.s_fwd * p->hp.s_fwd));
+  a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+  return ffc_dispatch<DkLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+}

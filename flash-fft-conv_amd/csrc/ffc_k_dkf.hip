@@ -1,0 +1,45 @@
+// dk_f accumulation kernel (Modes::dkf) + ffc_conv_bwd_dkf.
+#include "ffc_dev.h"
+using namespace ffc;
+
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel(DkfArgs d) {
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevB, GEO, DT>::dkf(d, h, chunk);
+}
+template <class GEO, int DT>
+struct DkfLaunch {
+  static int run(const DkfArgs& d, hipStream_t st) {
+    static int rc = ffc_set_lds(dkf_kernel<GEO, DT>, GEO::LDS_BYTES);
+    if (rc) return rc;
+    int hpad = (d.c.H + 7) & ~7;
+    hipLaunchKernelGGL((dkf_kernel<GEO, DT>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffc_fail(std::string("dkf_kernel launch: ") + hipGetErrorString(e));
+  }
+};
+
+extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t H) {
+  if (!p) return 0;
+  int nchunk, ppc;
+  ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
+  int upw = 8 / p->hp.NW;
+  return (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
+}
+
+extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void* u, const void* pregate, const void* postgate,
+                                void* ws, int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!p || !dout || !u || !ws) return ffc_fail("null arg");
+  if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
+  if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
+  if (B * H * L >= ((int64_t)1 << 31)) return ffc_fail("tensor too large (>= 2^31 elements)");
+  DkfArgs d{};
+  ConvArgs& a = d.c;
+  a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
+  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
+  ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  d.dout = dout; d.ws = (float*)ws;
+  return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
+}

@@ -1,0 +1,30 @@
+// k -> k_f kernel (Modes::kfft) + ffc_kernel_fft.
+#include "ffc_dev.h"
+using namespace ffc;
+
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void kfft_kernel(KfArgs a) {
+  Modes<DevB, GEO, DT>::kfft(a, blockIdx.x);
+}
+template <class GEO, int DT>
+struct KfLaunch {
+  static int run(const KfArgs& a, hipStream_t st) {
+    static int rc = ffc_set_lds(kfft_kernel<GEO, DT>, GEO::LDS_BYTES);
+    if (rc) return rc;
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    hipLaunchKernelGGL((kfft_kernel<GEO, DT>), dim3((nunits + GEO::UPW - 1) / GEO::UPW), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffc_fail(std::string("kfft_kernel launch: ") + hipGetErrorString(e));
+  }
+};
+
+extern "C" int ffc_kernel_fft(const ffc_plan* p, const float* k, int64_t H, int64_t Lk, void* kf, void* stream) {
+  if (!p || !k || !kf) return ffc_fail("null arg");
+  if (H <= 0 || Lk <= 0 || Lk > p->hp.N) return ffc_fail("k must be (H, Lk) with 0 < Lk <= fft_size");
+  if (H * Lk >= ((int64_t)1 << 31)) return ffc_fail("k too large");
+  KfArgs a{};
+  a.k = k; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = (int)Lk;
+  a.scale = (float)(p->hp.s_k / p->hp.s_fwd);
+  a.fast = (Lk % 4 == 0) && !((uintptr_t)k & 15);
+  return ffc_dispatch<KfLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+}

@@ -1,4 +1,424 @@
-// Additional kernel modes built from the same building blocks (k -> k_f, dk_f accumulation,
-// dk_f -> dk).  Filled in below.
+// Kernel modes built from the conv building blocks (ffc_body.h):
+//   kfft  : k (H,Lk) fp32 -> k_f in internal order           (replaces torch.fft.fft + permute + cast,
+//           reference flashfftconv/conv.py:572-575, :585, :676)
+//   dkf   : W[h] = sum_b FFT(dout*postgate) * conj(FFT(u*pregate)), fp32 partial slabs
+//           (reference: the dk_f half of kernels_bf16/*_bwd_kernel_bf16.h, which accumulates in bf16
+//           registers and reduces with dk_f_out.sum(0), monarch_cuda_interface_bwd_bf16.cu:1256-1264)
+//   dkifft: dk = Re(iFFT(sum of slabs))[:Lk]                   (reference conv.py:1758-1761, 1861-1864)
+// Pair packing keeps working for dk: with z_u = u_a + i u_b and z_d = d_a + i d_b,
+//   Re iFFT( Z_d * conj(Z_u) ) = corr(d_a,u_a) + corr(d_b,u_b).
 #pragma once
 #include "ffc_body.h"
+
+namespace ffc {
+
+struct KfArgs {
+  const float* k;      // (H, Lk) fp32
+  void* kf;            // (H, NT*1024, 2) dtype, internal order
+  const uint8_t* tab;
+  PlanTabs t;
+  int H, Lk;
+  float scale;         // s_k / s_fwd
+  int fast;            // Lk % 4 == 0 and 16-byte aligned
+};
+
+struct DkfArgs {
+  ConvArgs c;          // u / pregate / postgate as in the forward; c.y unused
+  const void* dout;
+  float* ws;           // [nchunk*UPW][H][NT*1024][2] fp32 partial sums (internal order)
+};
+
+struct DkArgs {
+  const float* ws;
+  float* dk;           // (H, Lk) fp32
+  const uint8_t* tab;
+  PlanTabs t;
+  int H, Lk, nslab;
+  float scale;         // 1 / (N * s_fwd^2)
+  int fast;
+};
+
+template <class B, class GEO, int DT>
+struct Modes : Body<B, GEO, DT> {
+  using BD = Body<B, GEO, DT>;
+  using f32 = typename B::f32;
+  using i32 = typename B::i32;
+  using u32 = typename B::u32;
+  using pred = typename B::pred;
+  using U2 = typename B::U2;
+  using U4 = typename B::U4;
+  using Unit = typename BD::Unit;
+  using Op = typename BD::Op;
+  using InnerRegs = typename BD::InnerRegs;
+
+  // ------------------------------------------------------------------ k -> k_f
+  // 8 fp32 starting at element e0 (per lane) of base, zero beyond `lim` (per lane limit on e0+i)
+  static FFC_FN void fload8(const float* base, i32 e0, i32 n, int lim, bool fast, pred ok, f32 (&v)[8]) {
+    if (fast) {
+      U4 a = B::g_r128p(base, e0 >> 2, ok && (n < lim));
+      U4 b = B::g_r128p(base, (e0 >> 2) + 1, ok && ((n + 4) < lim));
+      v[0] = B::as_f32(a.x); v[1] = B::as_f32(a.y); v[2] = B::as_f32(a.z); v[3] = B::as_f32(a.w);
+      v[4] = B::as_f32(b.x); v[5] = B::as_f32(b.y); v[6] = B::as_f32(b.z); v[7] = B::as_f32(b.w);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[q] = B::as_f32(B::g_r32(base, e0 + q, ok && ((n + q) < lim)));
+    }
+  }
+  static FFC_FN void k_rows_in(const KfArgs& a, int unit_id, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      pred sw;
+      i32 off = BD::pair_off(row, m, &sw) + un.eb;
+      i32 hd, n;
+      if constexpr (GEO::OUTER) { hd = row * 0 + unit_id; n = row * GEO::Mi + m; }
+      else { hd = row + unit_id * GEO::G; n = m; }
+      pred ok = hd < a.H;
+      f32 v[8];
+      fload8(a.k, hd * a.Lk + n, n, a.Lk, a.fast != 0, ok, v);
+      U4 o;
+      u32 p0 = B::template pack<DT>(v[0], v[1]), p1 = B::template pack<DT>(v[2], v[3]);
+      u32 p2 = B::template pack<DT>(v[4], v[5]), p3 = B::template pack<DT>(v[6], v[7]);
+      o.x = B::sel(sw, p2, p0); o.y = B::sel(sw, p3, p1); o.z = B::sel(sw, p0, p2); o.w = B::sel(sw, p1, p3);
+      B::lds_w128(off, o, B::ptrue());
+      U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
+      B::lds_w128(off + GEO::PLANE, z, B::ptrue());
+    }
+  }
+  static FFC_FN void kf_store(const KfArgs& a, int unit_id, int tau, const f32 (&re)[16], const f32 (&im)[16]) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      U4 v;
+      u32 w[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) w[q] = B::template pack<DT>(re[4 * rq + q] * a.scale, im[4 * rq + q] * a.scale);
+      v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+      if constexpr (GEO::OUTER) {
+        pred ok = (c * 0 + unit_id) < a.H;
+        i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) + unit_id * (GEO::NT * 256);
+        B::g_w128(a.kf, idx, v, ok);
+      } else {
+        // the tile holds G heads (sub-blocks); each head's k_f tile replicates its block G times
+        i32 V = hi * 4 + 8 * rq;
+        i32 sV = V / GEO::N3, k3 = V % GEO::N3, sU = c / GEO::N2, k2 = c % GEO::N2;
+        i32 hd = sU * GEO::SV + sV + unit_id * GEO::G;
+        pred ok = hd < a.H;
+#pragma unroll
+        for (int su = 0; su < GEO::SU; su++)
+#pragma unroll
+          for (int sv = 0; sv < GEO::SV; sv++) {
+            i32 rho = (k3 + sv * GEO::N3) >> 2;
+            i32 idx = (rho * 32 + (k2 + su * GEO::N2)) + hd * 256;
+            B::g_w128(a.kf, idx, v, ok);
+          }
+      }
+    }
+  }
+  // one workgroup: UPW units (heads, or tiles of G heads)
+  static FFC_FN void kfft(const KfArgs& a, int wg) {
+    BD::setup_tables(a.tab, a.t);
+    const int wv = B::wave();
+    Unit un;
+    un.wq = wv % GEO::NW;
+    const int u = wv / GEO::NW;
+    un.eb = u * GEO::EBYTES;
+    const int unit_id = wg * GEO::UPW + u;
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    const bool act = unit_id < nunits;
+    InnerRegs R;
+    BD::load_inner(R);
+    if constexpr (GEO::OUTER) {
+      if (act) {
+        k_rows_in(a, unit_id, un);
+        B::lds_fence();
+        if (GEO::S1 == 1 && 16 * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un);
+        else BD::template outer_stage<true, false>(a.Lk, un);
+      }
+      B::barrier();
+      if (act) {
+#pragma unroll 1
+        for (int tt = 0; tt < GEO::TPW; tt++) {
+          f32 re[16], im[16];
+          BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+          kf_store(a, unit_id, un.wq * GEO::TPW + tt, re, im);
+        }
+      }
+    } else {
+      if (act) {
+        k_rows_in(a, unit_id, un);
+        B::lds_fence();
+        f32 re[16], im[16];
+        BD::tile_fwd(0, R, un, re, im);
+        kf_store(a, unit_id, 0, re, im);
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ dk_f accumulation
+  static FFC_FN void w_accum(float* slab, int tau, bool first, const Op& zv, const f32 (&re)[16], const f32 (&im)[16]) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2;   // 16-byte units: 2 complex fp32 each
+      f32 wr[4], wi[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * rq + q;
+        u32 pr = zv.r[r >> 3][(r & 7) >> 1], pi = zv.i[r >> 3][(r & 7) >> 1];
+        f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
+        f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
+        // Zd * conj(Zv)
+        wr[q] = re[r] * ur + im[r] * ui;
+        wi[q] = im[r] * ur - re[r] * ui;
+      }
+      if (!first) {
+        U4 o0 = B::g_r128(slab, idx), o1 = B::g_r128(slab, idx + 1);
+        wr[0] = wr[0] + B::as_f32(o0.x); wi[0] = wi[0] + B::as_f32(o0.y);
+        wr[1] = wr[1] + B::as_f32(o0.z); wi[1] = wi[1] + B::as_f32(o0.w);
+        wr[2] = wr[2] + B::as_f32(o1.x); wi[2] = wi[2] + B::as_f32(o1.y);
+        wr[3] = wr[3] + B::as_f32(o1.z); wi[3] = wi[3] + B::as_f32(o1.w);
+      }
+      U4 n0, n1;
+      n0.x = B::as_u32(wr[0]); n0.y = B::as_u32(wi[0]); n0.z = B::as_u32(wr[1]); n0.w = B::as_u32(wi[1]);
+      n1.x = B::as_u32(wr[2]); n1.y = B::as_u32(wi[2]); n1.z = B::as_u32(wr[3]); n1.w = B::as_u32(wi[3]);
+      B::g_w128(slab, idx, n0, B::ptrue());
+      B::g_w128(slab, idx + 1, n1, B::ptrue());
+    }
+  }
+  static FFC_FN void w_zero(float* slab, int tau) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2;
+      B::g_w128(slab, idx, z, B::ptrue());
+      B::g_w128(slab, idx + 1, z, B::ptrue());
+    }
+  }
+  static FFC_FN void dkf(const DkfArgs& d, int h, int chunk) {
+    const ConvArgs& a = d.c;
+    BD::setup_tables(a.tab, a.t);
+    const int wv = B::wave();
+    Unit un;
+    un.wq = wv % GEO::NW;
+    const int u = wv / GEO::NW;
+    un.eb = u * GEO::EBYTES;
+    const int p0 = chunk * a.ppc;
+    int p1 = p0 + a.ppc;
+    if (p1 > a.npair) p1 = a.npair;
+    ConvArgs av = a;            // v = u * pregate
+    ConvArgs ad = a;            // dc = dout * postgate
+    ad.u = d.dout; ad.pregate = a.postgate;
+    float* slab = d.ws + ((int64_t)(chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    InnerRegs R;
+    if constexpr (GEO::OUTER) {
+      const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int p = p0 + it * GEO::UPW + u;
+        const bool act = p < p1;
+        if (act) {
+          BD::rows_in(av, h, p, un);
+          B::lds_fence();
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
+          else BD::template outer_stage<true, false>(a.L, un);
+        }
+        B::barrier();
+        Op zv[GEO::TPW];
+        if (act) {
+          BD::load_inner(R);
+#pragma unroll
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            f32 re[16], im[16];
+            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            BD::to_op(re, im, zv[tt]);
+          }
+        }
+        B::barrier();
+        if (act) {
+          BD::rows_in(ad, h, p, un);
+          B::lds_fence();
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
+          else BD::template outer_stage<true, false>(a.L, un);
+        }
+        B::barrier();
+        if (act) {
+          BD::load_inner(R);
+#pragma unroll
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            f32 re[16], im[16];
+            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            w_accum(slab, un.wq * GEO::TPW + tt, it == 0, zv[tt], re, im);
+          }
+        } else if (it == 0) {
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
+        }
+        B::barrier();
+      }
+    } else {
+      const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
+      const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
+      BD::load_inner(R);
+      f32 wre[16], wim[16];
+      BD::zero(wre); BD::zero(wim);
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int q = q0 + it * GEO::UPW + u;
+        if (q < q1) {
+          Op zv;
+          f32 re[16], im[16];
+          BD::rows_in(av, h, q, un);
+          B::lds_fence();
+          BD::tile_fwd(0, R, un, re, im);
+          BD::to_op(re, im, zv);
+          B::lds_fence();
+          BD::rows_in(ad, h, q, un);
+          B::lds_fence();
+          BD::tile_fwd(0, R, un, re, im);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            u32 pr = zv.r[r >> 3][(r & 7) >> 1], pi = zv.i[r >> 3][(r & 7) >> 1];
+            f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
+            f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
+            wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
+            wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
+          }
+          B::lds_fence();
+        }
+      }
+      store_w(slab, wre, wim);
+    }
+  }
+  static FFC_FN void store_w(float* slab, const f32 (&re)[16], const f32 (&im)[16]) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + 2 * rq) * 32 + c) * 2;
+      U4 n0, n1;
+      n0.x = B::as_u32(re[4 * rq]); n0.y = B::as_u32(im[4 * rq]); n0.z = B::as_u32(re[4 * rq + 1]); n0.w = B::as_u32(im[4 * rq + 1]);
+      n1.x = B::as_u32(re[4 * rq + 2]); n1.y = B::as_u32(im[4 * rq + 2]); n1.z = B::as_u32(re[4 * rq + 3]); n1.w = B::as_u32(im[4 * rq + 3]);
+      B::g_w128(slab, idx, n0, B::ptrue());
+      B::g_w128(slab, idx + 1, n1, B::ptrue());
+    }
+  }
+
+  // ------------------------------------------------------------------ dk_f -> dk
+  static FFC_FN void w_load(const DkArgs& a, int unit_id, int tau, f32 (&re)[16], f32 (&im)[16]) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    const int64_t slab_stride = (int64_t)a.H * (GEO::NT * 2048);   // floats
+    BD::zero(re); BD::zero(im);
+#pragma unroll 1
+    for (int s = 0; s < a.nslab; s++) {
+      const float* sl = a.ws + s * slab_stride;
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        if constexpr (GEO::OUTER) {
+          i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2 + unit_id * (GEO::NT * 512);
+          U4 o0 = B::g_r128(sl, idx), o1 = B::g_r128(sl, idx + 1);
+          re[4 * rq] = re[4 * rq] + B::as_f32(o0.x); im[4 * rq] = im[4 * rq] + B::as_f32(o0.y);
+          re[4 * rq + 1] = re[4 * rq + 1] + B::as_f32(o0.z); im[4 * rq + 1] = im[4 * rq + 1] + B::as_f32(o0.w);
+          re[4 * rq + 2] = re[4 * rq + 2] + B::as_f32(o1.x); im[4 * rq + 2] = im[4 * rq + 2] + B::as_f32(o1.y);
+          re[4 * rq + 3] = re[4 * rq + 3] + B::as_f32(o1.z); im[4 * rq + 3] = im[4 * rq + 3] + B::as_f32(o1.w);
+        } else {
+          i32 V = hi * 4 + 8 * rq;
+          i32 sV = V / GEO::N3, k3 = V % GEO::N3, sU = c / GEO::N2, k2 = c % GEO::N2;
+          i32 hd = sU * GEO::SV + sV + unit_id * GEO::G;
+          pred ok = hd < a.H;
+#pragma unroll
+          for (int su = 0; su < GEO::SU; su++)
+#pragma unroll
+            for (int sv = 0; sv < GEO::SV; sv++) {
+              i32 rho = (k3 + sv * GEO::N3) >> 2;
+              i32 idx = (rho * 32 + (k2 + su * GEO::N2)) * 2 + hd * 512;
+              U4 o0 = B::g_r128p(sl, idx, ok), o1 = B::g_r128p(sl, idx + 1, ok);
+              re[4 * rq] = re[4 * rq] + B::as_f32(o0.x); im[4 * rq] = im[4 * rq] + B::as_f32(o0.y);
+              re[4 * rq + 1] = re[4 * rq + 1] + B::as_f32(o0.z); im[4 * rq + 1] = im[4 * rq + 1] + B::as_f32(o0.w);
+              re[4 * rq + 2] = re[4 * rq + 2] + B::as_f32(o1.x); im[4 * rq + 2] = im[4 * rq + 2] + B::as_f32(o1.y);
+              re[4 * rq + 3] = re[4 * rq + 3] + B::as_f32(o1.z); im[4 * rq + 3] = im[4 * rq + 3] + B::as_f32(o1.w);
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) { re[r] = re[r] * a.scale; im[r] = im[r] * a.scale; }
+  }
+  static FFC_FN void dk_rows_out(const DkArgs& a, int unit_id, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      pred sw;
+      i32 off = BD::pair_off(row, m, &sw) + un.eb;
+      U4 o = B::lds_r128(off);
+      u32 w[4];
+      w[0] = B::sel(sw, o.z, o.x); w[1] = B::sel(sw, o.w, o.y); w[2] = B::sel(sw, o.x, o.z); w[3] = B::sel(sw, o.y, o.w);
+      i32 hd, n;
+      if constexpr (GEO::OUTER) { hd = row * 0 + unit_id; n = row * GEO::Mi + m; }
+      else { hd = row + unit_id * GEO::G; n = m; }
+      pred ok = hd < a.H;
+      i32 e0 = hd * a.Lk + n;
+      f32 v[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { v[2 * q] = B::template unpack_lo<DT>(w[q]); v[2 * q + 1] = B::template unpack_hi<DT>(w[q]); }
+      if (a.fast) {
+        U4 s0, s1;
+        s0.x = B::as_u32(v[0]); s0.y = B::as_u32(v[1]); s0.z = B::as_u32(v[2]); s0.w = B::as_u32(v[3]);
+        s1.x = B::as_u32(v[4]); s1.y = B::as_u32(v[5]); s1.z = B::as_u32(v[6]); s1.w = B::as_u32(v[7]);
+        B::g_w128(a.dk, e0 >> 2, s0, ok && (n < a.Lk));
+        B::g_w128(a.dk, (e0 >> 2) + 1, s1, ok && ((n + 4) < a.Lk));
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) B::g_w32(a.dk, e0 + q, B::as_u32(v[q]), ok && ((n + q) < a.Lk));
+      }
+    }
+  }
+  static FFC_FN void dkifft(const DkArgs& a, int wg) {
+    BD::setup_tables(a.tab, a.t);
+    const int wv = B::wave();
+    Unit un;
+    un.wq = wv % GEO::NW;
+    const int u = wv / GEO::NW;
+    un.eb = u * GEO::EBYTES;
+    const int unit_id = wg * GEO::UPW + u;
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    const bool act = unit_id < nunits;
+    InnerRegs R;
+    BD::load_inner(R);
+    if constexpr (GEO::OUTER) {
+      if (act) {
+#pragma unroll 1
+        for (int tt = 0; tt < GEO::TPW; tt++) {
+          f32 re[16], im[16];
+          w_load(a, unit_id, un.wq * GEO::TPW + tt, re, im);
+          BD::tile_inv(a.tab, a.t, un.wq * GEO::TPW + tt, R, un, re, im);
+        }
+      }
+      B::barrier();
+      if (act) {
+        BD::template outer_stage<false, false>(a.Lk, un);
+        B::lds_fence();
+        dk_rows_out(a, unit_id, un);
+      }
+    } else {
+      if (act) {
+        f32 re[16], im[16];
+        w_load(a, unit_id, 0, re, im);
+        BD::tile_inv(a.tab, a.t, 0, R, un, re, im);
+        B::lds_fence();
+        dk_rows_out(a, unit_id, un);
+      }
+    }
+  }
+};
+
+}  // namespace ffc

@@ -137,6 +137,14 @@ struct SimB {
   static void g_w16(void* base, const i32& e, const u32& v, const pred& p) {
     for (int i = 0; i < 64; i++) if (p.v[i]) { uint16_t h = (uint16_t)v.v[i]; memcpy((uint8_t*)base + (int64_t)e.v[i] * 2, &h, 2); }
   }
+  static u32 g_r32(const void* base, const i32& e, const pred& p) {
+    u32 r;
+    for (int i = 0; i < 64; i++) { uint32_t h = 0; if (p.v[i]) memcpy(&h, (const uint8_t*)base + (int64_t)e.v[i] * 4, 4); r.v[i] = h; }
+    return r;
+  }
+  static void g_w32(void* base, const i32& e, const u32& v, const pred& p) {
+    for (int i = 0; i < 64; i++) if (p.v[i]) memcpy((uint8_t*)base + (int64_t)e.v[i] * 4, &v.v[i], 4);
+  }
   static U2 g_r64(const void* base, const i32& o8, const pred& p) {
     U2 r;
     for (int i = 0; i < 64; i++) {
@@ -246,6 +254,28 @@ static int dispatch(int N, int dtype, A&&... args) {
   return -1;
 }
 template <class GEO, int DT> struct ConvRun { static void run(const ConvArgs& a) { sim_conv_t<GEO, DT>(a); } };
+template <class GEO, int DT> struct KfRun {
+  static void run(const KfArgs& a) {
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    for (int wg = 0; wg < (nunits + GEO::UPW - 1) / GEO::UPW; wg++)
+      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::kfft(a, wg); });
+  }
+};
+template <class GEO, int DT> struct DkfRun {
+  static void run(const DkfArgs& d) {
+    for (int h = 0; h < d.c.H; h++)
+      for (int c = 0; c < d.c.nchunk; c++)
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkf(d, h, c); });
+  }
+};
+template <class GEO, int DT> struct DkRun {
+  static void run(const DkArgs& a) {
+    const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
+    for (int wg = 0; wg < (nunits + GEO::UPW - 1) / GEO::UPW; wg++)
+      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkifft(a, wg); });
+  }
+};
+template <class GEO, int DT> struct UpwGet { static void run(int* out) { *out = GEO::UPW; } };
 
 }  // namespace ffc
 
@@ -306,6 +336,48 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf;
   a.fast = (L % 8 == 0) && !g_force_slow;
   return dispatch<ConvRun>(N, dtype, a);
+}
+
+
+int ffcsim_upw(int N) { int u = 0; dispatch<UpwGet>(N, 0, &u); return u; }
+
+int ffcsim_kernel_fft(int N, int dtype, const float* k, int H, int Lk, void* kf) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  KfArgs a{};
+  a.k = k; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk;
+  a.scale = (float)(p.s_k / p.s_fwd); a.fast = (Lk % 4 == 0) && !g_force_slow;
+  return dispatch<KfRun>(N, dtype, a);
+}
+
+// ws must hold nchunk*UPW*H*NT*2048 floats
+int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const void* pregate, const void* postgate,
+                        float* ws, int B, int H, int L, int nchunk) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  DkfArgs d{};
+  ConvArgs& a = d.c;
+  a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
+  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
+  int upw = ffcsim_upw(N);
+  int per_iter = p.N1 > 1 ? upw : upw * p.G;
+  int iters_total = (a.npair + per_iter - 1) / per_iter;
+  if (nchunk > iters_total) nchunk = iters_total;
+  int ipc = (iters_total + nchunk - 1) / nchunk;
+  a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
+  a.fast = (L % 8 == 0) && !g_force_slow;
+  d.dout = dout; d.ws = ws;
+  int rc = dispatch<DkfRun>(N, dtype, d);
+  return rc < 0 ? rc : a.nchunk * upw;   // number of slabs written
+}
+
+int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H, int Lk, float* dk) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  DkArgs a{};
+  a.ws = ws; a.dk = dk; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk; a.nslab = nslab;
+  a.scale = (float)(1.0 / ((double)N * p.s_fwd * p.s_fwd)); a.fast = (Lk % 4 == 0) && !g_force_slow;
+  return dispatch<DkRun>(N, dtype, a);
 }
 
 }  // extern "C"

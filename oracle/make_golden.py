@@ -1,0 +1,72 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own oracle source (run in the build container,
+where /root/reference exists; the fixtures travel, /root/reference does not).
+
+The reference package cannot be imported (it needs the CUDA extension monarch_cuda), so the pure
+torch functions are extracted by AST from
+  /root/reference/tests/test_flashfftconv.py        ref_fft_conv         (lines 5-13)
+  /root/reference/benchmarks/benchmark_flashfftconv.py  ref_fftconv_gated  (lines 18-26)
+and executed on CPU with the reference's input recipe (test_flashfftconv.py:54-64: randn*0.02,
+k decayed by exp(-0.1 t)), gradients through torch autograd exactly like the reference tests."""
+import ast, os, sys
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def extract(path, names):
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def main():
+    (ref_fft_conv,) = extract(os.path.join(REF, "tests/test_flashfftconv.py"), ["ref_fft_conv"])
+    (ref_gated,) = extract(os.path.join(REF, "benchmarks/benchmark_flashfftconv.py"), ["ref_fftconv_gated"])
+    os.makedirs(OUT, exist_ok=True)
+    cases = [  # (N, L, B, H, dtype, gated)
+        (256, 256, 3, 4, torch.bfloat16, False), (256, 128, 2, 4, torch.float16, True),
+        (512, 512, 2, 3, torch.bfloat16, True), (1024, 512, 4, 8, torch.bfloat16, False),
+        (1024, 1024, 2, 2, torch.float16, False), (4096, 2048, 3, 2, torch.bfloat16, True),
+        (4096, 4096, 2, 2, torch.float16, False), (8192, 4096, 2, 2, torch.bfloat16, False),
+        (16384, 8192, 2, 2, torch.bfloat16, True), (32768, 16384, 2, 2, torch.bfloat16, False),
+        (32768, 32768, 1, 2, torch.float16, True),
+    ]
+    for (N, L, B, H, dtype, gated) in cases:
+        g = torch.Generator().manual_seed(N + L + B)
+        u = (torch.randn(B, H, L, generator=g).to(dtype) * 0.02)
+        k = torch.randn(H, L, generator=g) * 0.02 * torch.exp(-0.1 * torch.arange(L))
+        if L == N:  # reference test_flash_fft_conv zeroes the second half (causal == circular)
+            u[..., N // 2:] = 0; k[..., N // 2:] = 0
+        dout = (torch.randn(B, H, L, generator=g).to(dtype) * 0.02)
+        u = u.clone().requires_grad_(True); k = k.clone().requires_grad_(True)
+        if gated:
+            # unit-scale gates (the reference tests use *0.02, which pushes fp16 outputs into the
+            # subnormal range where only the absolute tolerance is meaningful)
+            pre = torch.randn(B, H, L, generator=g).to(dtype).requires_grad_(True)
+            post = torch.randn(B, H, L, generator=g).to(dtype).requires_grad_(True)
+            # reference gated test: ref_fft_conv(u * pregate, k) * postgate (test_flashfftconv.py:205)
+            out = ref_fft_conv(u * pre, k, n=N) * post
+            out2 = ref_gated(u.detach().float(), k.detach(), N, pre.detach().float(), post.detach().float())
+            assert torch.allclose(out.float(), out2.float()[..., :L], atol=1e-4)
+        else:
+            out = ref_fft_conv(u, k, n=N)
+        out.backward(dout)
+        d = dict(N=N, L=L, dtype=str(dtype).split(".")[-1], gated=int(gated),
+                 u=u.detach().float().numpy(), k=k.detach().numpy(), dout=dout.float().numpy(),
+                 out=out.detach().float().numpy(), du=u.grad.float().numpy(), dk=k.grad.numpy())
+        if gated:
+            d.update(pre=pre.detach().float().numpy(), post=post.detach().float().numpy(),
+                     dpre=pre.grad.float().numpy(), dpost=post.grad.float().numpy())
+        name = f"conv_N{N}_L{L}_B{B}_H{H}_{d['dtype']}_{'gated' if gated else 'plain'}.npz"
+        np.savez_compressed(os.path.join(OUT, name), **d)
+        print("wrote", name)
+
+
+if __name__ == "__main__":
+    main()

@@ -77,3 +77,27 @@ def sim_conv_fwd(N, dtype, u_bits, kf_bits, pre=None, post=None, conj=0):
     rc = lib().ffcsim_conv_fwd(N, dtype, p(u_bits), p(kf_bits), p(pre), p(post), p(y), B, H, L, conj)
     assert rc == 0, rc
     return y
+
+
+def sim_kernel_fft(N, dtype, k):
+    k = np.ascontiguousarray(k, np.float32)
+    H, Lk = k.shape
+    nt, _, _, _ = plan_info(N, dtype)
+    kf = np.zeros((H, nt * 1024, 2), np.uint16)
+    rc = lib().ffcsim_kernel_fft(N, dtype, p(k), H, Lk, p(kf))
+    assert rc == 0, rc
+    return kf
+
+
+def sim_dk(N, dtype, dout_bits, u_bits, Lk, pre=None, post=None, nchunk=1):
+    """dk (H, Lk) fp32 through the simulated dkf + dkifft kernels."""
+    B, H, L = u_bits.shape
+    nt, _, _, _ = plan_info(N, dtype)
+    upw = lib().ffcsim_upw(N)
+    ws = np.full(max(nchunk, 1) * upw * H * nt * 2048, np.nan, np.float32)
+    nslab = lib().ffcsim_conv_bwd_dkf(N, dtype, p(dout_bits), p(u_bits), p(pre), p(post), p(ws), B, H, L, nchunk)
+    assert nslab > 0, nslab
+    dk = np.full((H, Lk), np.nan, np.float32)
+    rc = lib().ffcsim_kernel_ifft_grad(N, dtype, p(ws), nslab, H, Lk, p(dk))
+    assert rc == 0, rc
+    return dk

@@ -1,0 +1,50 @@
+"""The CPU oracle is pinned against golden vectors generated from the REFERENCE's own oracle source
+(oracle/make_golden.py), and against the structure-faithful restatement of the reference's Monarch
+factorisation (oracle/monarch_ref.py)."""
+import glob, os
+import numpy as np
+import pytest
+
+from oracle import ref_fft_conv as O
+from oracle import monarch_ref as M
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_*.npz")))
+DT = {"bfloat16": "bf16", "float16": "fp16"}
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[5:-4] for p in GOLD])
+def test_oracle_matches_reference_golden(path):
+    g = np.load(path)
+    N, dt = int(g["N"]), DT[str(g["dtype"])]
+    if int(g["gated"]):
+        out = O.ref_fft_conv_gated(g["u"], g["k"], g["pre"], g["post"], N, dtype=dt)
+        du, dk, dpre, dpost = O.ref_grads(g["u"], g["k"], g["dout"], N, g["pre"], g["post"])
+    else:
+        out = O.ref_fft_conv(g["u"], g["k"], N)
+        du, dk = O.ref_grads(g["u"], g["k"], g["dout"], N)
+    # golden outputs were rounded to bf16/fp16 by the reference oracle (".to(u.dtype)")
+    tol = 6e-3 if dt == "bf16" else 8e-4
+    assert rel(out, g["out"].astype(np.float64)) < tol
+    assert rel(du, g["du"].astype(np.float64)) < 2 * tol
+    assert rel(dk, g["dk"].astype(np.float64)) < 2 * tol     # fp32 in the reference
+    if int(g["gated"]):
+        assert rel(dpre, g["dpre"].astype(np.float64)) < 2 * tol
+        assert rel(dpost, g["dpost"].astype(np.float64)) < 2 * tol
+
+
+@pytest.mark.parametrize("N", [256, 1024])
+def test_reference_monarch_2stage_equals_fft(N):
+    rng = np.random.default_rng(N)
+    u = rng.standard_normal((2, 3, N // 2)); k = rng.standard_normal((3, N // 2))
+    assert rel(M.monarch_conv_2stage(u, k, N), O.ref_fft_conv(u, k, N)) < 1e-10
+
+
+@pytest.mark.parametrize("N,n1,n2", [(4096, 16, 16), (8192, 32, 16), (16384, 16, 32), (32768, 32, 32)])
+def test_reference_monarch_3stage_equals_fft(N, n1, n2):
+    rng = np.random.default_rng(N)
+    u = rng.standard_normal((1, 2, N // 2)); k = rng.standard_normal((2, N // 2))
+    assert rel(M.monarch_conv_3stage(u, k, N, n1, n2), O.ref_fft_conv(u, k, N)) < 1e-10

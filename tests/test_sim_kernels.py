@@ -1,0 +1,119 @@
+"""Kernel logic on CPU: the SAME kernel body the GPU runs (ffc_body.h / ffc_modes.h) is executed by
+the 64-lane wave simulator (csrc/ffc_sim.cpp) and compared with the oracle."""
+import numpy as np
+import pytest
+
+import simlib as S
+from oracle import ref_fft_conv as O
+
+SIZES = [256, 512, 1024, 4096, 8192, 16384, 32768]
+TOL = {0: 1.2e-2, 1: 1.5e-3}     # rel-L2 gates: bf16, fp16
+NAME = {0: "bf16", 1: "fp16"}
+
+
+def rel(a, b):
+    a = np.asarray(a)
+    a = a.astype(np.complex128) if np.iscomplexobj(a) else a.astype(np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def q(x, dt):
+    return S.from_bits(S.to_bits(x, dt), dt).astype(np.float64)
+
+
+@pytest.mark.parametrize("N", SIZES)
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("padded", [False, True])
+def test_conv_fwd(N, dt, padded):
+    rng = np.random.default_rng(N + dt)
+    L = N // 2 if padded else N
+    B, H = 3, 2                      # odd batch: last pair has an empty imaginary lane
+    u = rng.standard_normal((B, H, L)).astype(np.float32)
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)          # k -> k_f through the simulated kfft kernel
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf), dt)
+    assert rel(y, O.ref_fft_conv(q(u, dt), k, N)) < TOL[dt]
+
+
+@pytest.mark.parametrize("N", [256, 1024, 4096, 32768])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_conv_gated_and_conj(N, dt):
+    rng = np.random.default_rng(7 * N + dt)
+    L, B, H = N // 2, 2, 2
+    u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.make_kf_internal(k, N, dt)
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, S.to_bits(g1, dt), S.to_bits(g2, dt)), dt)
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype=NAME[dt])
+    assert rel(y, ref) < TOL[dt]
+    # conj(k_f): the input-gradient pass
+    du = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, conj=1), dt)
+    dref, _ = O.ref_grads(np.zeros_like(u), k, q(u, dt), N)
+    assert rel(du, dref) < TOL[dt]
+
+
+@pytest.mark.parametrize("N,L", [(256, 2), (256, 250), (1024, 1002), (4096, 2050), (8192, 36), (32768, 16390)])
+def test_conv_ragged_lengths(N, L):
+    """L not a multiple of 8 takes the element-wise I/O path; tiny and odd-ish lengths included."""
+    rng = np.random.default_rng(L)
+    u = rng.standard_normal((2, 2, L)).astype(np.float32)
+    k = (rng.standard_normal((2, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, 0, k)
+    y = S.from_bits(S.sim_conv_fwd(N, 0, S.to_bits(u, 0), kf), 0)
+    assert rel(y, O.ref_fft_conv(q(u, 0), k, N)) < TOL[0]
+
+
+def test_linearity_and_shift_properties():
+    """Size-independent properties: conv is linear in u and commutes with a delay."""
+    N, L, dt = 4096, 2048, 0
+    rng = np.random.default_rng(3)
+    k = (rng.standard_normal((1, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    imp = np.zeros((2, 1, L), np.float32); imp[0, 0, 0] = 1.0; imp[1, 0, 5] = 1.0
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(imp, dt), kf), dt)
+    assert rel(y[0, 0], k[0].astype(np.float64)) < TOL[dt]                 # identity impulse -> k
+    assert rel(y[1, 0, 5:], k[0, :-5].astype(np.float64)) < TOL[dt]        # delayed impulse -> delayed k
+    assert np.abs(y[1, 0, :5]).max() < 1e-3
+
+
+@pytest.mark.parametrize("N", SIZES)
+@pytest.mark.parametrize("dt", [0, 1])
+def test_kernel_fft(N, dt):
+    rng = np.random.default_rng(N)
+    H, Lk = 5, N // 2 + 4
+    k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
+    got = S.from_bits(S.sim_kernel_fft(N, dt, k), dt)
+    got = got[..., 0] + 1j * got[..., 1]
+    nt, sf, sk, freq = S.plan_info(N, dt)
+    ref = np.fft.fft(k.astype(np.float64), n=N, axis=-1)[:, freq] * sk
+    assert rel(got, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("N,L,B,H,nch,gated", [(256, 128, 20, 2, 2, True), (512, 512, 3, 2, 1, False), (1024, 512, 6, 3, 1, True),
+                                               (4096, 4096, 18, 1, 2, True), (8192, 4096, 3, 2, 1, False),
+                                               (16384, 16384, 5, 1, 2, False), (32768, 16384, 4, 2, 2, True)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_dk_path(N, L, B, H, nch, gated, dt):
+    """dk_f accumulation (fp32 slabs, several chunks) + inverse -> dk, vs analytic gradient."""
+    rng = np.random.default_rng(N + B)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    Lk = L - 4
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    dk = S.sim_dk(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), Lk, pre, post, nchunk=nch)
+    v = q(q(u, dt) * q(g1, dt), dt) if gated else q(u, dt)
+    dc = q(q(d, dt) * q(g2, dt), dt) if gated else q(d, dt)
+    ref = np.fft.ifft((np.fft.fft(dc, n=N) * np.conj(np.fft.fft(v, n=N))).sum(0)).real[:, :Lk]
+    assert rel(dk, ref) < 1.5 * TOL[dt]
+
+
+def test_golden_forward_through_simulator():
+    """Committed golden vectors (reference oracle outputs) vs the simulated kernels."""
+    import glob, os
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_N*_plain.npz")))[:4]:
+        g = np.load(path)
+        N = int(g["N"]); dt = 0 if str(g["dtype"]) == "bfloat16" else 1
+        kf = S.sim_kernel_fft(N, dt, g["k"])
+        y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(g["u"], dt), kf), dt)
+        assert rel(y, g["out"].astype(np.float64)) < TOL[dt] * 1.5, path
+        assert np.allclose(y, g["out"], atol=1e-2)      # the reference's own assert (test_flashfftconv.py:83)
