@@ -44,12 +44,12 @@ def test_conv1d_fwd(b, d, l, k, in_dtype, w_dtype, is_bhl):
 @pytest.mark.parametrize("is_bhl", [True, False])
 def test_conv1d_bwd(b, d, l, k, in_dtype, w_dtype, is_bhl):
     ref, m, x = make(b, d, l, k, in_dtype, w_dtype, is_bhl)
-    xq = x.to(in_dtype)
-    xr = xq.float().requires_grad_(True)
+    xq = x.to(in_dtype).detach().clone()
+    xr = xq.float().detach().clone().requires_grad_(True)
     y_ref = ref(xr)
     dout = torch.randn_like(y_ref)
     y_ref.backward(dout)
-    xin = (xq if is_bhl else xq.transpose(1, 2).contiguous()).requires_grad_(True)
+    xin = (xq if is_bhl else xq.transpose(1, 2)).contiguous().detach().clone().requires_grad_(True)
     y = m(xin)
     y.backward((dout if is_bhl else dout.transpose(1, 2).contiguous()).to(in_dtype))
     dx = xin.grad if is_bhl else xin.grad.transpose(1, 2)
