@@ -142,7 +142,9 @@ __device__ __forceinline__ bool map_block(int H, int nchunk, int* h, int* chunk)
 
 struct ffc_plan {
   ffc::HostPlan hp;
+  ffc::HostPlan hp_bf;          // bf16 tables for the dk inverse (fp32 dynamic range), == hp for bf16 plans
   uint8_t* d_blob = nullptr;
+  uint8_t* d_blob_bf = nullptr;
   int32_t* d_freq = nullptr;
   int num_cu = 256;
 };

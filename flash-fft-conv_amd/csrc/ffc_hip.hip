@@ -62,6 +62,14 @@ int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
   }
   hipError_t e = hipMalloc((void**)&p->d_blob, p->hp.blob.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_blob, p->hp.blob.data(), p->hp.blob.size(), hipMemcpyHostToDevice);
+  if (dtype == DT_BF16) {
+    p->hp_bf = p->hp;
+    p->d_blob_bf = p->d_blob;
+  } else {
+    build_plan((int)fft_size, DT_BF16, &p->hp_bf);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_blob_bf, p->hp_bf.blob.size());
+    if (e == hipSuccess) e = hipMemcpy(p->d_blob_bf, p->hp_bf.blob.data(), p->hp_bf.blob.size(), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void**)&p->d_freq, p->hp.kf_freq.size() * 4);
   if (e == hipSuccess) e = hipMemcpy(p->d_freq, p->hp.kf_freq.data(), p->hp.kf_freq.size() * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -78,6 +86,7 @@ int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
 
 void ffc_plan_destroy(ffc_plan* p) {
   if (!p) return;
+  if (p->d_blob_bf && p->d_blob_bf != p->d_blob) (void)hipFree(p->d_blob_bf);
   if (p->d_blob) (void)hipFree(p->d_blob);
   if (p->d_freq) (void)hipFree(p->d_freq);
   delete p;

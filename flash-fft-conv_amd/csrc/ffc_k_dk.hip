@@ -24,9 +24,10 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   DkArgs a{};
-  a.ws = (const float*)ws; a.dk = dk; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = (int)Lk;
+  // always bf16 arithmetic: W/N underflows fp16 for small gradients, bf16 keeps fp32's range
+  a.ws = (const float*)ws; a.dk = dk; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = (int)Lk;
   a.nslab = nchunk * (8 / p->hp.NW);
   a.scale = (float)(1.0 / ((double)p->hp.N * p->hp.s_fwd * p->hp.s_fwd));
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
-  return ffc_dispatch<DkLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+  return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }

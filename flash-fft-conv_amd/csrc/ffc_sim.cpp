@@ -373,6 +373,8 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
 
 int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H, int Lk, float* dk) {
   HostPlan p;
+  (void)dtype;                      // the dk inverse always runs in bf16 arithmetic (see ffc_k_dk.hip)
+  dtype = DT_BF16;
   if (!build_plan(N, dtype, &p)) return -1;
   DkArgs a{};
   a.ws = ws; a.dk = dk; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk; a.nslab = nslab;
