@@ -27,7 +27,7 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   // always bf16 arithmetic: W/N underflows fp16 for small gradients, bf16 keeps fp32's range
   a.ws = (const float*)ws; a.dk = dk; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = (int)Lk;
   a.nslab = nchunk * (8 / p->hp.NW);
-  a.scale = (float)(1.0 / ((double)p->hp.N * p->hp.s_fwd * p->hp.s_fwd));
+  a.scale = (float)(1.0 / p->hp.s_fwd);   // tile_inv already applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }

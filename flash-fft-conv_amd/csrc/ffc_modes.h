@@ -34,7 +34,7 @@ struct DkArgs {
   const uint8_t* tab;
   PlanTabs t;
   int H, Lk, nslab;
-  float scale;         // 1 / (N * s_fwd^2)
+  float scale;         // 1 / s_fwd  (W carries s_fwd^2, the inverse applies 1/(N s_fwd))
   int fast;
 };
 

@@ -154,7 +154,11 @@ void build(HostPlan* p) {
   int lg = 0;
   while ((1 << lg) < N) lg++;
   p->s_fwd = ldexp(1.0, -((lg + 1) / 2));
-  p->s_k = 1.0 / ((double)N * p->s_fwd);
+  // forward carries s_fwd ~ 1/sqrt(N) (spectrum RMS ~ input RMS), k_f is stored unscaled and the
+  // remaining 1/(N*s_fwd) is applied in fp32 at the last inner inverse twiddle, so that no
+  // intermediate drifts into the fp16 subnormal range.
+  p->s_k = 1.0;
+  p->s_inv = 1.0 / ((double)N * p->s_fwd);
   PlanTabs& t = p->tabs;
   int digits[3] = {GEO::N1, GEO::N2, GEO::N3};
   for (int i = 0; i < 3; i++) {
@@ -170,7 +174,7 @@ void build(HostPlan* p) {
   t.twin2 = bl.alloc(8192);
   fill_ctab16(p->blob.data() + t.twin2, [&](int lane, int r, double* re, double* im) {
     int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
-    cis((double)(n3 * k2), GEO::Mi, 1.0, re, im);
+    cis((double)(n3 * k2), GEO::Mi, GEO::OUTER ? 1.0 : p->s_inv, re, im);
   });
   t.base = bl.alloc(8192);
   t.delta = bl.alloc(256);
@@ -203,7 +207,7 @@ void build(HostPlan* p) {
           int sU = c / GEO::N2, n2 = c % GEO::N2;
           int k1 = tau * GEO::G + sU * GEO::SV + sV;
           double re, im;
-          cis((double)(n2 * GEO::N3) * k1, N, 1.0, &re, &im);
+          cis((double)(n2 * GEO::N3) * k1, N, p->s_inv, &re, &im);
           a[((tau * 32 + c) * GEO::SV + sV) * 2] = (float)re;
           a[((tau * 32 + c) * GEO::SV + sV) * 2 + 1] = (float)im;
         }

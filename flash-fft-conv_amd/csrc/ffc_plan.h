@@ -21,7 +21,7 @@ struct PlanTabs {      // byte offsets into the plan blob
 struct HostPlan {
   int N = 0, N1 = 0, N2 = 0, N3 = 0, dtype = 0;
   int NT = 0, NW = 0, G = 0;
-  double s_fwd = 1, s_k = 1;
+  double s_fwd = 1, s_k = 1, s_inv = 1;   // s_fwd * s_k * s_inv == 1/N
   PlanTabs tabs{};
   std::vector<uint8_t> blob;
   std::vector<int32_t> kf_freq;  // internal position -> natural frequency, NT*1024 entries

@@ -378,7 +378,7 @@ int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H,
   if (!build_plan(N, dtype, &p)) return -1;
   DkArgs a{};
   a.ws = ws; a.dk = dk; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk; a.nslab = nslab;
-  a.scale = (float)(1.0 / ((double)N * p.s_fwd * p.s_fwd)); a.fast = (Lk % 4 == 0) && !g_force_slow;
+  a.scale = (float)(1.0 / p.s_fwd);   // tile_inv already applies s_inv = 1/(N s_fwd) a.fast = (Lk % 4 == 0) && !g_force_slow;
   return dispatch<DkRun>(N, dtype, a);
 }
 

@@ -104,7 +104,7 @@ def test_dk_path(N, L, B, H, nch, gated, dt):
     v = q(q(u, dt) * q(g1, dt), dt) if gated else q(u, dt)
     dc = q(q(d, dt) * q(g2, dt), dt) if gated else q(d, dt)
     ref = np.fft.ifft((np.fft.fft(dc, n=N) * np.conj(np.fft.fft(v, n=N))).sum(0)).real[:, :Lk]
-    assert rel(dk, ref) < 1.5 * TOL[dt]
+    assert rel(dk, ref) < 1.5 * TOL[0]       # the dk inverse always runs in bf16 arithmetic (fp32 range)
 
 
 def test_golden_forward_through_simulator():
