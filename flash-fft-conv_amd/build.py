@@ -6,7 +6,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 HIP_SO = os.path.join(LIB, "libflashfftconv_hip.so")
 SIM_SO = os.path.join(LIB, "libffcsim.so")
-HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
+HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
 

@@ -10,6 +10,7 @@
 #include "../../include/flashfftconv_hip.h"
 #include "ffc_body.h"
 #include "ffc_modes.h"
+#include "ffc_big.h"
 
 namespace ffc {
 
@@ -58,6 +59,9 @@ struct DevB {
   }
   static FFC_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   static FFC_FN u32 uconst(uint32_t c) { return c; }
+  static FFC_FN f32 i2f(i32 a) { return (float)a; }
+  static FFC_FN f32 cos_rev(f32 x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: argument in revolutions
+  static FFC_FN f32 sin_rev(f32 x) { return __builtin_amdgcn_sinf(x); }
   // hide a value from LICM/CSE so per-phase address math is recomputed instead of kept live
   static FFC_FN i32 opaque(i32 x) { asm volatile("" : "+v"(x)); return x; }
   static FFC_FN u32 sel(pred p, u32 a, u32 b) { return p ? a : b; }

@@ -19,6 +19,7 @@ struct KfArgs {
   PlanTabs t;
   int H, Lk;
   float scale;         // s_k / s_fwd
+  const void* xpair;   // optional complex input instead of k: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;            // Lk % 4 == 0 and 16-byte aligned
 };
 
@@ -35,6 +36,7 @@ struct DkArgs {
   PlanTabs t;
   int H, Lk, nslab;
   float scale;         // 1 / s_fwd  (W carries s_fwd^2, the inverse applies 1/(N s_fwd))
+  void* outpair;       // optional complex output instead of dk: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;
 };
 
@@ -133,7 +135,13 @@ struct Modes : Body<B, GEO, DT> {
     BD::load_inner(R);
     if constexpr (GEO::OUTER) {
       if (act) {
-        k_rows_in(a, unit_id, un);
+        if (a.xpair) {
+          ConvArgs cv{};
+          cv.u = a.xpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1;
+          BD::rows_in(cv, unit_id, 0, un);
+        } else {
+          k_rows_in(a, unit_id, un);
+        }
         B::lds_fence();
         if (GEO::S1 == 1 && 16 * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un);
         else BD::template outer_stage<true, false>(a.Lk, un);
@@ -407,7 +415,13 @@ struct Modes : Body<B, GEO, DT> {
       if (act) {
         BD::template outer_stage<false, false>(a.Lk, un);
         B::lds_fence();
-        dk_rows_out(a, unit_id, un);
+        if (a.outpair) {
+          ConvArgs cv{};
+          cv.y = a.outpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1;
+          BD::rows_out(cv, unit_id, 0, un);
+        } else {
+          dk_rows_out(a, unit_id, un);
+        }
       }
     } else {
       if (act) {

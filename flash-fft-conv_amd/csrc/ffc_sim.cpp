@@ -16,6 +16,7 @@
 #define FFC_FN inline __attribute__((always_inline))
 #include "ffc_body.h"
 #include "ffc_modes.h"
+#include "ffc_big.h"
 
 namespace ffc {
 
@@ -126,6 +127,9 @@ struct SimB {
     return r;
   }
   static void lds_fence() {}
+  static f32 i2f(const i32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)a.v[i]; return r; }
+  static f32 cos_rev(const f32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)cos(6.283185307179586 * (double)a.v[i]); return r; }
+  static f32 sin_rev(const f32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)sin(6.283185307179586 * (double)a.v[i]); return r; }
   static i32 opaque(const i32& x) { return x; }
   static u32 uconst(uint32_t c) { return u32(c); }
   static u32 sel(const pred& p, const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] ? a.v[i] : b.v[i]; return r; }
@@ -339,7 +343,38 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
 }
 
 
+// HBM-level outer pass (ffc_big.h).  fwd: in = long side (Bp_valid rows, Hin, Llong), out = (2*npair, Hin*N0, Mi).
+int ffcsim_big_outer(int N0, int dtype, int fwd, const void* in, void* out, const void* gate, int Bp_valid, int npair,
+                     int Hin, int Mi, int Llong, float scale) {
+  HostPlan p;
+  if (!build_plan(N0 == 16 ? 16384 : 32768, dtype, &p)) return -1;   // only for the N0-point operand table
+  BigArgs a{};
+  a.in = in; a.out = out; a.gate = gate; a.fmat = p.blob.data() + p.tabs.mat[0];
+  a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
+  a.fast = (Llong % 8 == 0) && !g_force_slow;
+  const int cols = 1024 * (32 / N0);
+  if (Mi % cols) return -2;
+  const int nwg = npair * Hin * (Mi / cols);
+  for (int wg = 0; wg < nwg; wg++) {
+#define FFC_BIG(NN, DD, FF) run_wg(8, GeoBig<NN>::LDS_BYTES, [&]() { BigBody<SimB, NN, DD>::template run<FF>(a, wg); })
+    if (N0 == 16) { if (dtype == DT_BF16) { if (fwd) FFC_BIG(16, DT_BF16, true); else FFC_BIG(16, DT_BF16, false); }
+                    else { if (fwd) FFC_BIG(16, DT_F16, true); else FFC_BIG(16, DT_F16, false); } }
+    else { if (dtype == DT_BF16) { if (fwd) FFC_BIG(32, DT_BF16, true); else FFC_BIG(32, DT_BF16, false); }
+           else { if (fwd) FFC_BIG(32, DT_F16, true); else FFC_BIG(32, DT_F16, false); } }
+#undef FFC_BIG
+  }
+  return 0;
+}
+
 int ffcsim_upw(int N) { int u = 0; dispatch<UpwGet>(N, 0, &u); return u; }
+
+int ffcsim_kernel_fft_c(int N, int dtype, const void* xpair, int H, void* kf, float scale) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  KfArgs a{};
+  a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.fast = 1;
+  return dispatch<KfRun>(N, dtype, a);
+}
 
 int ffcsim_kernel_fft(int N, int dtype, const float* k, int H, int Lk, void* kf) {
   HostPlan p;
@@ -369,6 +404,14 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   d.dout = dout; d.ws = ws;
   int rc = dispatch<DkfRun>(N, dtype, d);
   return rc < 0 ? rc : a.nchunk * upw;   // number of slabs written
+}
+
+int ffcsim_kernel_ifft_grad_c(int N, const float* ws, int nslab, int H, void* outpair, float scale) {
+  HostPlan p;
+  if (!build_plan(N, DT_BF16, &p)) return -1;
+  DkArgs a{};
+  a.ws = ws; a.outpair = outpair; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.nslab = nslab; a.scale = scale; a.fast = 1;
+  return dispatch<DkRun>(N, DT_BF16, a);
 }
 
 int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H, int Lk, float* dk) {

@@ -1,0 +1,102 @@
+"""FFT sizes 65536 .. 4194304: one or two HBM-level outer DFT passes (factor 16 or 32, csrc/ffc_big.h)
+around the fused kernel of size M <= 32768.  Mirrors the reference's butterfly -> inner complex
+monarch -> butterfly_ifft chain (flashfftconv/conv.py:692-1732, :1867-2002, :3340-4958) but
+ * every level packs two batch rows as one complex sequence (no real/complex kernel split),
+ * the inner kernel is the SAME fused kernel: the complex intermediate is stored as a
+   "pair-plane" tensor (2*pairs, H*prod(N0), M) whose rows 2p/2p+1 are Re/Im, which is exactly the
+   (B, H, L) layout the fused kernel already consumes with "heads" = (head, k0).
+The functions are written against an `ops` object (GPU: flashfftconv.conv._TorchOps, CPU tests: the
+wave simulator) so the index/scale bookkeeping is verified without a GPU."""
+
+# N -> (outer factors, fused inner size)
+BIG_FACTORS = {
+    65536: ((16,), 4096),
+    131072: ((32,), 4096),
+    262144: ((16,), 16384),
+    524288: ((16,), 32768),
+    1048576: ((32,), 32768),
+    2097152: ((16, 16), 8192),
+    4194304: ((16, 16), 16384),
+}
+
+
+def level_scale(n0):
+    """forward scale of one level ~ 1/sqrt(N0) (keeps the spectrum RMS near the input RMS)"""
+    return 0.25 if n0 == 16 else 0.125
+
+
+def inner_sfwd(M):
+    lg = M.bit_length() - 1
+    return 2.0 ** (-((lg + 1) // 2))
+
+
+def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None):
+    """x: (B_valid, H, L) long-side tensor -> (2*npair, H*prod(N0), M) pair-plane tensor."""
+    factors, M = BIG_FACTORS[N]
+    npair = (B_valid + 1) // 2
+    Hx, nlev, Llong, bv = H, N, L, B_valid
+    for i, n0 in enumerate(factors):
+        mi = nlev // n0
+        out = ops.empty_pair(dt, 2 * npair, Hx * n0, mi)
+        ops.outer(dt, n0, True, x, out, gate if i == 0 else None, bv, npair, Hx, mi, Llong, level_scale(n0))
+        x, Hx, nlev, Llong, bv = out, Hx * n0, mi, mi, 2 * npair
+    return x
+
+
+def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None):
+    """y: (2*npair, H*prod(N0), M) -> out (B_valid, H, L) (written in place).  `shared` caches the
+    intermediate of the two-level case so several gated outputs reuse it."""
+    factors, M = BIG_FACTORS[N]
+    npair = y.shape[0] // 2
+    Hx = H
+    for n0 in factors:
+        Hx *= n0
+    nlev = M
+    cur = y
+    for i in reversed(range(len(factors))):
+        n0 = factors[i]
+        Hx //= n0
+        nlev *= n0
+        sc = 1.0 / (n0 * level_scale(n0))
+        if i == 0:
+            ops.outer(dt, n0, False, cur, out, gate, B_valid, npair, Hx, nlev // n0, L, sc)
+        else:
+            if shared is not None and "mid" in shared:
+                cur = shared["mid"]
+            else:
+                mid = ops.empty_pair(dt, 2 * npair, Hx, nlev)
+                ops.outer(dt, n0, False, cur, mid, None, 2 * npair, npair, Hx, nlev // n0, nlev, sc)
+                cur = mid
+                if shared is not None:
+                    shared["mid"] = mid
+    return out
+
+
+def prod_scale(N):
+    factors, M = BIG_FACTORS[N]
+    s = 1.0
+    for n0 in factors:
+        s *= level_scale(n0)
+    return s
+
+
+def kernel_fft(ops, dt, N, k, H, Lk):
+    """k (H, Lk) fp32 -> inner k_f rows (H*prod(N0), M-internal), unscaled K_f."""
+    factors, M = BIG_FACTORS[N]
+    kx = ops.to_dtype_rows(dt, k, H, Lk)            # (1, H, Lk) dtype
+    x = levels_forward(ops, dt, N, kx, 1, H, Lk)
+    hp = x.shape[1]
+    return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N)))
+
+
+def dk_from_slabs(ops, N, ws, Bp, H, Lk):
+    """fp32 W slabs of the inner size -> dk (H, Lk) fp32.  Always bf16 arithmetic (fp32 range)."""
+    factors, M = BIG_FACTORS[N]
+    hp = H
+    for n0 in factors:
+        hp *= n0
+    BF = ops.BF16
+    y = ops.dkifft_c(M, ws, Bp, hp, 1.0 / (inner_sfwd(M) * prod_scale(N)))     # (2, hp, M) bf16
+    out = ops.empty_pair(BF, 1, H, Lk)
+    levels_inverse(ops, BF, N, y, out, 1, H, Lk)
+    return ops.to_float_rows(out, H, Lk)

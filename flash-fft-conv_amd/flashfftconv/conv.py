@@ -11,9 +11,11 @@ import ctypes
 import torch
 
 from . import _lib
+from . import bigfft as _big
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
-SUPPORTED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
+FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
+SUPPORTED_SEQLENS = FUSED_SEQLENS + tuple(sorted(_big.BIG_FACTORS))
 
 
 class _Plan:
@@ -52,6 +54,94 @@ def _kernel_fft(plan, k):
     return kf
 
 
+class _TorchOps:
+    """GPU backend of flashfftconv.bigfft (FFT sizes >= 65536): thin wrappers over the C-ABI."""
+    BF16 = torch.bfloat16
+
+    def __init__(self, mod, device):
+        self.mod, self.device = mod, device
+
+    def _plan(self, N):
+        return self.mod._get_plan(self.device, N)
+
+    def empty_pair(self, dt, Bp, Hx, n):
+        return torch.empty(Bp, Hx, n, dtype=dt, device=self.device)
+
+    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+        p16, p32 = self._plan(16384), self._plan(32768)
+        _lib.check(_lib.lib().ffc_outer_pass(p16.handle, p32.handle, n0, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out),
+                                             _lib.ptr(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale),
+                                             _lib.stream_ptr()), "ffc_outer_pass")
+
+    def to_dtype_rows(self, dt, k, H, Lk):
+        return k.detach().to(dt).reshape(1, H, Lk).contiguous()
+
+    def to_float_rows(self, out, H, Lk):
+        return out[0].float()
+
+    def kfft_c(self, dt, M, x, hp, scale):
+        plan = self._plan(M)
+        kf = torch.empty(hp, plan.kf_elems, 2, dtype=dt, device=self.device)
+        _lib.check(_lib.lib().ffc_kernel_fft_c(plan.handle, _lib.ptr(x), hp, _lib.ptr(kf), ctypes.c_float(scale),
+                                               _lib.stream_ptr()), "ffc_kernel_fft_c")
+        return kf
+
+    def conv(self, dt, M, x, kf, conj):
+        return _conv(self._plan(M), x, kf, None, None, conj)
+
+    def dkf(self, dt, M, xd, xu):
+        plan = self._plan(M)
+        Bp, hp, _ = xu.shape
+        lib = _lib.lib()
+        ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, Bp, hp), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(xd), _lib.ptr(xu), None, None, _lib.ptr(ws), Bp, hp, M,
+                                        _lib.stream_ptr()), "ffc_conv_bwd_dkf")
+        return ws
+
+    def dkifft_c(self, M, ws, Bp, hp, scale):
+        plan = self._plan(M)
+        out = torch.empty(2, hp, M, dtype=torch.bfloat16, device=self.device)
+        _lib.check(_lib.lib().ffc_kernel_ifft_grad_c(plan.handle, _lib.ptr(ws), Bp, hp, _lib.ptr(out), ctypes.c_float(scale),
+                                                     _lib.stream_ptr()), "ffc_kernel_ifft_grad_c")
+        return out
+
+
+def _big_forward(mod, u, k, pregate, postgate):
+    N, dt = mod.seqlen, mod.dtype
+    ops = _TorchOps(mod, u.device)
+    B, H, L = u.shape
+    M = _big.BIG_FACTORS[N][1]
+    kf = _big.kernel_fft(ops, dt, N, k.detach().to(torch.float32).contiguous(), H, k.shape[-1])
+    x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
+    y = ops.conv(dt, M, x, kf, False)
+    out = torch.empty_like(u)
+    _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate)
+    return out, kf
+
+
+def _big_backward(mod, dout, u, kf, pregate, postgate, k_len):
+    N, dt = mod.seqlen, mod.dtype
+    ops = _TorchOps(mod, u.device)
+    B, H, L = u.shape
+    M = _big.BIG_FACTORS[N][1]
+    xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate)
+    xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
+    ws = ops.dkf(dt, M, xd, xu)
+    dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
+    yd = ops.conv(dt, M, xd, kf, True)
+    du = torch.empty_like(u)
+    shared = {}
+    _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared)
+    if pregate is None:
+        return du, dk, None, None
+    dpre = torch.empty_like(u)
+    _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared)
+    yu = ops.conv(dt, M, xu, kf, False)
+    dpost = torch.empty_like(u)
+    _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout)
+    return du, dk, dpre, dpost
+
+
 def _check_inputs(mod, u, k, gates):
     if not u.is_cuda:
         raise RuntimeError("FlashFFTConv: u must be a CUDA/HIP tensor (no CPU fallback in the product path)")
@@ -75,29 +165,37 @@ class _FlashFFTConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, k, mod, pregate, postgate):
         _check_inputs(mod, u, k, (pregate, postgate))
-        plan = mod._get_plan(u.device)
         u = u.contiguous()
         pregate = None if pregate is None else pregate.contiguous()
         postgate = None if postgate is None else postgate.contiguous()
-        kf = _kernel_fft(plan, k)
-        ctx.plan, ctx.k_len, ctx.k_dtype, ctx.gated = plan, k.shape[-1], k.dtype, pregate is not None
+        ctx.mod, ctx.k_len, ctx.k_dtype, ctx.gated = mod, k.shape[-1], k.dtype, pregate is not None
+        ctx.big = mod.seqlen in _big.BIG_FACTORS
+        if ctx.big:
+            out, kf = _big_forward(mod, u, k, pregate, postgate)
+        else:
+            plan = mod._get_plan(u.device)
+            kf = _kernel_fft(plan, k)
+            out = _conv(plan, u, kf, pregate, postgate, False)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             if ctx.gated:
                 ctx.save_for_backward(u, kf, pregate, postgate)
             else:
                 ctx.save_for_backward(u, kf)
-        return _conv(plan, u, kf, pregate, postgate, False)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.saved_tensors:
             raise RuntimeError("FlashFFTConv: backward needs module.training=True at forward time")
-        plan = ctx.plan
         dout = dout.contiguous()
         if ctx.gated:
             u, kf, pregate, postgate = ctx.saved_tensors
         else:
             (u, kf), pregate, postgate = ctx.saved_tensors, None, None
+        if ctx.big:
+            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len)
+            return du, dk.to(ctx.k_dtype), None, dpre, dpost
+        plan = ctx.mod._get_plan(u.device)
         B, H, L = u.shape
         lib = _lib.lib()
         # dk: fp32 accumulation of FFT(dout*postgate) * conj(FFT(u*pregate)) over the batch, then inverse
@@ -131,11 +229,12 @@ class FlashFFTConv(torch.nn.Module):
         self.use_32_butterfly = use_32_butterfly
         self._plans = {}
 
-    def _get_plan(self, device):
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    def _get_plan(self, device, N=None):
+        N = self.seqlen if N is None else N
+        key = (N, device.type, device.index if device.index is not None else torch.cuda.current_device())
         p = self._plans.get(key)
         if p is None:
-            p = _Plan(self.seqlen, self.dtype, device)
+            p = _Plan(N, self.dtype, device)
             self._plans[key] = p
         return p
 

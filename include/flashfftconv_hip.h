@@ -55,6 +55,20 @@ int ffc_conv_bwd_dkf(const ffc_plan* plan, const void* dout, const void* u, cons
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);
 
+/* FFT sizes 65536..4194304 = one or two outer DFT levels (factor n0 = 16 or 32) through HBM around a
+ * fused inner size (replaces butterfly_{,padded_}{,gated_}{,ifft_}*forward, monarch.cpp:41-56, and the
+ * *_complex monarch exports :22-38).  The host chains the passes (flashfftconv/bigfft.py), exactly as
+ * reference conv.py:1420-1524 chains butterfly -> inner -> butterfly_ifft.
+ * dir=1: in (Bv,Hin,Llong) real/pair rows [* gate] -> out (2*npair, Hin*n0, Mi) pair-plane complex.
+ * dir=0: the inverse map, [* gate] applied to the output.  plan16/plan32: any plans whose outer digit
+ * is 16 / 32 (e.g. fft sizes 16384 / 32768), they supply the DFT tile in `dtype`. */
+int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int dtype, int dir, const void* in, void* out,
+                   const void* gate, int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale,
+                   void* stream);
+/* complex-input k_f and complex-output dk variants used by the big sizes (pair-plane tensors (2,H,N)). */
+int ffc_kernel_fft_c(const ffc_plan* plan, const void* xpair, int64_t H, void* kf_out, float scale, void* stream);
+int ffc_kernel_ifft_grad_c(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream);
+
 /* Short depthwise conv1d (reference csrc/flashfftconv/conv1d/conv1d.h:48-95).
  * in_dtype / w_dtype: 0 bf16, 1 fp16, 2 fp32.  is_bhl: u (B,D,L) w (D,K) else u (B,L,D) w (K,D). */
 int ffc_conv1d_fwd(const void* u, const void* w, const void* bias, void* y, int in_dtype, int w_dtype,

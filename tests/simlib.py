@@ -101,3 +101,51 @@ def sim_dk(N, dtype, dout_bits, u_bits, Lk, pre=None, post=None, nchunk=1):
     rc = lib().ffcsim_kernel_ifft_grad(N, dtype, p(ws), nslab, H, Lk, p(dk))
     assert rc == 0, rc
     return dk
+
+
+# ---------------------------------------------------------------- big FFT sizes on the simulator
+class SimOps:
+    """`ops` backend of flashfftconv.bigfft for the CPU wave simulator (numpy uint16 bit tensors)."""
+    BF16 = DT_BF16
+
+    def __init__(self):
+        self.nslab = None
+
+    def empty_pair(self, dt, Bp, Hx, n):
+        return np.zeros((Bp, Hx, n), np.uint16)
+
+    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+        rc = lib().ffcsim_big_outer(n0, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,
+                                    ctypes.c_float(scale))
+        assert rc == 0, rc
+
+    def to_dtype_rows(self, dt, k, H, Lk):
+        return to_bits(np.asarray(k, np.float32).reshape(1, H, Lk), dt)
+
+    def to_float_rows(self, out, H, Lk):
+        return from_bits(out, DT_BF16)[0].astype(np.float32)
+
+    def kfft_c(self, dt, M, x, hp, scale):
+        nt, _, _, _ = plan_info(M, dt)
+        kf = np.zeros((hp, nt * 1024, 2), np.uint16)
+        rc = lib().ffcsim_kernel_fft_c(M, dt, p(x), hp, p(kf), ctypes.c_float(scale))
+        assert rc == 0, rc
+        return kf
+
+    def conv(self, dt, M, x, kf, conj):
+        return sim_conv_fwd(M, dt, x, kf, conj=int(conj))
+
+    def dkf(self, dt, M, xd, xu):
+        Bp, hp, _ = xu.shape
+        nt, _, _, _ = plan_info(M, dt)
+        upw = lib().ffcsim_upw(M)
+        ws = np.full(upw * hp * nt * 2048, np.nan, np.float32)
+        self.nslab = lib().ffcsim_conv_bwd_dkf(M, dt, p(xd), p(xu), None, None, p(ws), Bp, hp, M, 1)
+        assert self.nslab > 0
+        return ws
+
+    def dkifft_c(self, M, ws, Bp, hp, scale):
+        out = np.zeros((2, hp, M), np.uint16)
+        rc = lib().ffcsim_kernel_ifft_grad_c(M, p(ws), self.nslab, hp, p(out), ctypes.c_float(scale))
+        assert rc == 0, rc
+        return out

@@ -14,9 +14,15 @@ SEQLENS = [256, 512, 1024, 4096, 8192, 16384, 32768]
 REL = {torch.bfloat16: 2e-2, torch.float16: 5e-3}   # SURVEY.md section 8(c) gates
 
 
-def set_B_H(B, H, seqlen):          # reference test_flashfftconv.py:15-46 (sizes we support)
+BIG = [65536, 131072, 262144, 524288, 1048576, 2097152, 4194304]
+
+
+def set_B_H(B, H, seqlen):          # reference test_flashfftconv.py:15-46
     if seqlen == 16384 and B > 32: B = 32
     if seqlen == 32768 and B > 16: B = 16
+    if seqlen >= 65536 and B > 4: B = 4
+    cap = {131072: 384, 262144: 192, 524288: 96, 1048576: 48, 2097152: 32, 4194304: 16}
+    if seqlen in cap and H > cap[seqlen]: H = cap[seqlen]
     return B, H
 
 
@@ -101,6 +107,19 @@ def test_flash_fft_conv_gating(B, H, seqlen, dtype):
 @pytest.mark.parametrize("B,H", [(2, 768), (3, 111)])
 def test_flash_fft_conv_gating_padded(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=True, gated=True)
+
+
+@pytest.mark.parametrize("seqlen", BIG)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("padded,gated", [(False, False), (True, False), (False, True), (True, True)])
+def test_flash_fft_conv_big(seqlen, dtype, padded, gated):
+    """N >= 65536 (reference tests/test_flashfftconv.py parametrisation up to 128*32768)."""
+    run_case(2, 32 if seqlen <= 1048576 else 16, seqlen, dtype, padded=padded, gated=gated)
+
+
+def test_big_odd_batch_small_heads():
+    run_case(3, 2, 65536, torch.bfloat16, padded=True, gated=False)
+    run_case(1, 3, 1048576, torch.bfloat16, padded=True, gated=False)
 
 
 def test_unit_scale_gated_relative():

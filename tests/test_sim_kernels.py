@@ -117,3 +117,29 @@ def test_golden_forward_through_simulator():
         y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(g["u"], dt), kf), dt)
         assert rel(y, g["out"].astype(np.float64)) < TOL[dt] * 1.5, path
         assert np.allclose(y, g["out"], atol=1e-2)      # the reference's own assert (test_flashfftconv.py:83)
+
+
+@pytest.mark.parametrize("N,L,B,gated", [(65536, 32768, 2, False), (131072, 131072, 1, True), (262144, 100004, 3, False)])
+def test_big_sizes_through_outer_levels(N, L, B, gated):
+    """FFT sizes >= 65536: HBM-level outer passes (csrc/ffc_big.h) + fused inner kernel, orchestrated by
+    flashfftconv/bigfft.py on the simulator backend; forward (gated / ragged / odd batch) and dk."""
+    from flashfftconv import bigfft as BG
+    rng = np.random.default_rng(N)
+    dt, H = 0, 1
+    ops = S.SimOps()
+    u, g1, g2, d = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.05).astype(np.float32)
+    ub, g1b, g2b, db = (S.to_bits(x, dt) for x in (u, g1, g2, d))
+    M = BG.BIG_FACTORS[N][1]
+    kf = BG.kernel_fft(ops, dt, N, k, H, L)
+    x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None)
+    y = ops.conv(dt, M, x, kf, False)
+    out = np.zeros_like(ub)
+    BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None)
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype="bf16") if gated else O.ref_fft_conv(q(u, dt), k, N)
+    assert rel(S.from_bits(out, dt), ref) < 1.5e-2
+    xu = BG.levels_forward(ops, dt, N, ub, B, H, L)
+    xd = BG.levels_forward(ops, dt, N, db, B, H, L)
+    dk = BG.dk_from_slabs(ops, N, ops.dkf(dt, M, xd, xu), xu.shape[0], H, L)
+    _, dkref = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(dk, dkref) < 1.5e-2
