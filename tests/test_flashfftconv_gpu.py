@@ -46,6 +46,8 @@ def make_inputs(B, H, L, N, dtype, half_zero, device="cuda"):
 
 def run_case(B, H, seqlen, dtype, padded, gated):
     from flashfftconv import FlashFFTConv
+    # big sizes add two bf16/fp16 roundings per outer level (through HBM) on each side
+    REL = {k: v * (2.0 if seqlen >= 65536 else 1.0) for k, v in globals()["REL"].items()}
     torch.manual_seed(0)
     B, H = set_B_H(B, H, seqlen)
     N = seqlen
