@@ -1,0 +1,85 @@
+"""BASELINE sweep: FlashFFTConv fwd, bwd, fwd+bwd for B=16, H=768, L in {1K..1M} (fft size 2L), plus the
+five BASELINE.json configs.  Where memory forces fewer heads the time is rescaled linearly to H=768
+(the reference does the same, benchmarks/benchmark_flashfftconv.py:28-59,111) and the row says so.
+Prints one JSON line per row.  Method mirrors reference benchmarks/benchmark.py (separate fwd / bwd
+timings, warm-up, mean over repeats) but with HIP events."""
+import json, math, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "flash-fft-conv_amd"), ROOT]
+import torch
+from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d
+
+
+def ev_time(fn, iters):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
+    Hrun = Hrun or H
+    dev = "cuda"
+    u = torch.randn(B, Hrun, L, device=dev).to(dtype).requires_grad_(True)
+    k = torch.randn(Hrun, L, device=dev).requires_grad_(True)
+    g = [torch.randn(B, Hrun, L, device=dev).to(dtype).requires_grad_(True) for _ in range(2)] if gated else []
+    dout = torch.randn(B, Hrun, L, device=dev).to(dtype)
+    mod = FlashFFTConv(N, dtype=dtype).to(dev)
+    iters = 20 if N <= 4096 else 10 if N <= 1048576 else 5
+    with torch.no_grad():
+        mod.eval()
+        t_f = ev_time(lambda: mod(u, k, *g), iters)
+        mod.train()
+    y = mod(u, k, *g)
+    t_b = ev_time(lambda: y.backward(dout, retain_graph=True), iters)
+    scale = H / Hrun
+    t_f, t_b = t_f * scale, t_b * scale
+    rows = B * H
+    lg = math.log2(N)
+    fft_f, fft_b = 2 * 5 * N * lg + 6 * N, 3 * 5 * N * lg + 14 * N
+    alg_f = B * H * L * 2 * (2 + 2 * gated) + H * N * 4
+    alg_b = B * H * L * 2 * (3 + 4 * gated) + H * N * 4 + H * N * 8
+    print(json.dumps({"row": name, "fft": N, "B": B, "H": H, "L": L, "dtype": str(dtype).split(".")[-1], "gated": gated,
+                      "H_run": Hrun, "rescaled": Hrun != H,
+                      "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4), "fwd_bwd_ms": round(t_f + t_b, 4),
+                      "seq_per_s": round(rows / ((t_f + t_b) * 1e-3)),
+                      "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
+                      "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9)}), flush=True)
+
+
+def conv1d_row():
+    import torch.nn as nn
+    B, D, L, K = 64, 2048, 8192, 3
+    ref = nn.Conv1d(D, D, K, groups=D, padding=1).cuda()
+    m = FlashDepthWiseConv1d(D, K, 1, ref.weight.detach(), ref.bias.detach(), is_bhl=True, device="cuda", dtype=torch.bfloat16)
+    x = torch.randn(B, D, L, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    with torch.no_grad():
+        t_f = ev_time(lambda: m(x), 10)
+    y = m(x)
+    dout = torch.randn_like(y)
+    t_b = ev_time(lambda: y.backward(dout, retain_graph=True), 5)
+    byts = B * L * D * 2 * 2 + K * D * 2
+    print(json.dumps({"row": "cfg5 conv1d k=3 B=64 H=2048 L=8192 bf16 BHL", "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
+                      "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9)}), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "configs"):
+        conv_row("cfg2 FlashFFTConv(32768) B16 H768 L16384", 32768, 16, 768, 16384)
+        conv_row("cfg3 gated fft16384 B8 H1024 L8192", 16384, 8, 1024, 8192, gated=True)
+        conv_row("cfg4 FlashFFTConv(4194304) B1 H16 L1048576", 4194304, 1, 16, 1048576)
+        conv1d_row()
+    if which in ("all", "sweep"):
+        for lg in range(10, 21):
+            L = 1 << lg
+            N = 2 * L
+            if N == 2048:
+                continue        # fft size 2048 not implemented yet
+            Hrun = 768 if N <= 131072 else max(16, 768 * 131072 // N)
+            conv_row(f"sweep L={L}", N, 16, 768, L, Hrun=Hrun)

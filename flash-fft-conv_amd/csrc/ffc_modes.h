@@ -18,7 +18,9 @@ struct KfArgs {
   const uint8_t* tab;
   PlanTabs t;
   int H, Lk;
-  float scale;         // s_k / s_fwd
+  float scale;         // s_k / (s_fwd * prescale)
+  float prescale;      // applied to k before rounding to dtype (2^8 in fp16 mode: k's energy sits in a few taps,
+                       // its scaled spectrum would otherwise fall into the fp16 subnormal range)
   const void* xpair;   // optional complex input instead of k: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;            // Lk % 4 == 0 and 16-byte aligned
 };
@@ -80,6 +82,8 @@ struct Modes : Body<B, GEO, DT> {
       pred ok = hd < a.H;
       f32 v[8];
       fload8(a.k, hd * a.Lk + n, n, a.Lk, a.fast != 0, ok, v);
+#pragma unroll
+      for (int q8 = 0; q8 < 8; q8++) v[q8] = v[q8] * a.prescale;
       U4 o;
       u32 p0 = B::template pack<DT>(v[0], v[1]), p1 = B::template pack<DT>(v[2], v[3]);
       u32 p2 = B::template pack<DT>(v[4], v[5]), p3 = B::template pack<DT>(v[6], v[7]);

@@ -372,7 +372,7 @@ int ffcsim_kernel_fft_c(int N, int dtype, const void* xpair, int H, void* kf, fl
   HostPlan p;
   if (!build_plan(N, dtype, &p)) return -1;
   KfArgs a{};
-  a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.fast = 1;
+  a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.prescale = 1.f; a.fast = 1;
   return dispatch<KfRun>(N, dtype, a);
 }
 
@@ -381,7 +381,8 @@ int ffcsim_kernel_fft(int N, int dtype, const float* k, int H, int Lk, void* kf)
   if (!build_plan(N, dtype, &p)) return -1;
   KfArgs a{};
   a.k = k; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk;
-  a.scale = (float)(p.s_k / p.s_fwd); a.fast = (Lk % 4 == 0) && !g_force_slow;
+  a.prescale = dtype == DT_F16 ? 256.f : 1.f;
+  a.scale = (float)(p.s_k / p.s_fwd) / a.prescale; a.fast = (Lk % 4 == 0) && !g_force_slow;
   return dispatch<KfRun>(N, dtype, a);
 }
 

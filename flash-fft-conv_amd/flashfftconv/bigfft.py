@@ -83,10 +83,11 @@ def prod_scale(N):
 def kernel_fft(ops, dt, N, k, H, Lk):
     """k (H, Lk) fp32 -> inner k_f rows (H*prod(N0), M-internal), unscaled K_f."""
     factors, M = BIG_FACTORS[N]
-    kx = ops.to_dtype_rows(dt, k, H, Lk)            # (1, H, Lk) dtype
+    pre = ops.k_prescale(dt)                         # 2^8 in fp16 mode (k's energy sits in a few taps)
+    kx = ops.to_dtype_rows(dt, k, H, Lk, pre)        # (1, H, Lk) dtype
     x = levels_forward(ops, dt, N, kx, 1, H, Lk)
     hp = x.shape[1]
-    return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N)))
+    return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N) * pre))
 
 
 def dk_from_slabs(ops, N, ws, Bp, H, Lk):

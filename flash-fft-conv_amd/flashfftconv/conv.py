@@ -73,8 +73,11 @@ class _TorchOps:
                                              _lib.ptr(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale),
                                              _lib.stream_ptr()), "ffc_outer_pass")
 
-    def to_dtype_rows(self, dt, k, H, Lk):
-        return k.detach().to(dt).reshape(1, H, Lk).contiguous()
+    def k_prescale(self, dt):
+        return 256.0 if dt == torch.float16 else 1.0
+
+    def to_dtype_rows(self, dt, k, H, Lk, pre=1.0):
+        return (k.detach() * pre).to(dt).reshape(1, H, Lk).contiguous()
 
     def to_float_rows(self, out, H, Lk):
         return out[0].float()

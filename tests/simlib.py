@@ -119,8 +119,11 @@ class SimOps:
                                     ctypes.c_float(scale))
         assert rc == 0, rc
 
-    def to_dtype_rows(self, dt, k, H, Lk):
-        return to_bits(np.asarray(k, np.float32).reshape(1, H, Lk), dt)
+    def k_prescale(self, dt):
+        return 256.0 if dt == DT_F16 else 1.0
+
+    def to_dtype_rows(self, dt, k, H, Lk, pre=1.0):
+        return to_bits(np.asarray(k, np.float32).reshape(1, H, Lk) * np.float32(pre), dt)
 
     def to_float_rows(self, out, H, Lk):
         return from_bits(out, DT_BF16)[0].astype(np.float32)
