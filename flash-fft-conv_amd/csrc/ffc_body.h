@@ -38,6 +38,7 @@ struct ConvArgs {
   int nchunk, ppc;       // chunks of pairs per head, pairs per chunk
   int conj_kf;           // 1: multiply by conj(k_f)  (input-gradient pass)
   int fast;              // 1: L % 8 == 0 and 16-byte aligned tensors -> 16-byte global accesses
+  float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
 };
 
 template <class B, class GEO, int DT>
@@ -48,17 +49,18 @@ struct Body {
   using pred = typename B::pred;
   using U2 = typename B::U2;
   using U4 = typename B::U4;
+  using A16 = typename B::A16;   // MFMA accumulator: 16 fp32 per lane (a native 16-register vector on the device)
+  using W4 = typename B::W4;     // MFMA operand: 8 x 16-bit per lane (4 dwords)
 
-  struct Mat { u32 w[2][3][4]; };   // [K-step][Fr,Fi,-Fi][dword]
+  struct Mat { W4 w[2][3]; };       // [K-step][Fr,Fi,-Fi]
   struct CT16 { f32 re[16], im[16]; };
-  struct Op { u32 r[2][4], i[2][4]; };  // complex MFMA data operand, 2 K-steps
+  struct Op { W4 r[2], i[2]; };     // complex MFMA data operand, 2 K-steps
 
   static FFC_FN void load_mat(Mat& m, const uint8_t* p, i32 lane) {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       U4 v = B::g_r128(p, lane + q * 64);
-      m.w[q / 3][q % 3][0] = v.x; m.w[q / 3][q % 3][1] = v.y;
-      m.w[q / 3][q % 3][2] = v.z; m.w[q / 3][q % 3][3] = v.w;
+      m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
     }
   }
   static FFC_FN void load_ct16(CT16& c, const uint8_t* p, i32 lane) {
@@ -69,21 +71,17 @@ struct Body {
       c.re[2 * rr + 1] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
     }
   }
-  static FFC_FN void zero(f32 (&a)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) a[r] = B::fconst(0.f);
-  }
   // acc += M (x) data.  AFORM: data is the MFMA A operand (its lane index moves to registers,
   // the transformed index lands on lanes).  !AFORM: matrix is A (transformed index in registers,
   // data lane index stays on lanes).  CONJ selects the inverse DFT.  ms_lim: K-steps to run.
   template <bool CONJ, bool AFORM>
-  static FFC_FN void cmm(f32 (&ore)[16], f32 (&oim)[16], const Op& d, const Mat& F, int ms_lim = 2) {
+  static FFC_FN void cmm(A16& ore, A16& oim, const Op& d, const Mat& F, int ms_lim = 2) {
 #pragma unroll
     for (int ms = 0; ms < 2; ms++) {
       if (ms >= ms_lim) continue;
-      const u32(&fr)[4] = F.w[ms][0];
-      const u32(&fi_re)[4] = F.w[ms][CONJ ? 1 : 2];  // multiplies data.im into re
-      const u32(&fi_im)[4] = F.w[ms][CONJ ? 2 : 1];  // multiplies data.re into im
+      const W4& fr = F.w[ms][0];
+      const W4& fi_re = F.w[ms][CONJ ? 1 : 2];  // multiplies data.im into re
+      const W4& fi_im = F.w[ms][CONJ ? 2 : 1];  // multiplies data.re into im
       if (AFORM) {
         B::template mfma<DT>(ore, d.r[ms], fr);
         B::template mfma<DT>(oim, d.r[ms], fi_im);
@@ -97,7 +95,7 @@ struct Body {
       }
     }
   }
-  static FFC_FN void to_op(const f32 (&re)[16], const f32 (&im)[16], Op& o) {
+  static FFC_FN void to_op(const A16& re, const A16& im, Op& o) {
 #pragma unroll
     for (int ms = 0; ms < 2; ms++)
 #pragma unroll
@@ -106,7 +104,7 @@ struct Body {
         o.i[ms][d] = B::template pack<DT>(im[8 * ms + 2 * d], im[8 * ms + 2 * d + 1]);
       }
   }
-  static FFC_FN void cmul(f32 (&re)[16], f32 (&im)[16], const CT16& t) {
+  static FFC_FN void cmul(A16& re, A16& im, const CT16& t) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       f32 a = re[r], b = im[r];
@@ -114,7 +112,7 @@ struct Body {
       im[r] = a * t.im[r] + b * t.re[r];
     }
   }
-  static FFC_FN void cmul_conj(f32 (&re)[16], f32 (&im)[16], const CT16& t) {
+  static FFC_FN void cmul_conj(A16& re, A16& im, const CT16& t) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       f32 a = re[r], b = im[r];
@@ -130,7 +128,7 @@ struct Body {
     return B::template pack<DT>(lo, hi);
   }
   // raw[e] holds 4 consecutive columns (tiles t=0..3) of k-slot e; build tile t's operand dwords.
-  static FFC_FN void xpose(const U2 (&raw)[8], int t, u32 (&op)[4]) {
+  static FFC_FN void xpose(const U2 (&raw)[8], int t, W4& op) {
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       u32 a = (t < 2) ? raw[2 * d].x : raw[2 * d].y;
@@ -140,7 +138,7 @@ struct Body {
   }
 
   // same with a runtime tile pair tp (x or y dword) and compile-time half th
-  static FFC_FN void xpose2(const U2 (&raw)[8], int tp, int th, u32 (&op)[4]) {
+  static FFC_FN void xpose2(const U2 (&raw)[8], int tp, int th, W4& op) {
 #pragma unroll
     for (int d = 0; d < 4; d++) {
       u32 a = tp ? raw[2 * d].y : raw[2 * d].x;
@@ -177,8 +175,7 @@ struct Body {
 #pragma unroll
     for (int q = 0; q < 6; q++) {
       U4 v = B::lds_r128(lane * 16 + (off + q * 1024));
-      m.w[q / 3][q % 3][0] = v.x; m.w[q / 3][q % 3][1] = v.y;
-      m.w[q / 3][q % 3][2] = v.z; m.w[q / 3][q % 3][3] = v.w;
+      m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
     }
   }
   static FFC_FN void lds_ct16(CT16& c, int off) {
@@ -250,7 +247,31 @@ struct Body {
   static constexpr int CPR = GEO::OUTER ? 16 * GEO::S1 : GEO::Mi / 8;   // 16-B chunks per row per wave
   static constexpr int NCH = GEO::OUTER ? 8 : 2;                        // chunks per lane per plane
 
-  static FFC_FN void rows_in(const ConvArgs& a, int h, int pq, Unit un) {
+  struct RowRegs { U4 v[NCH][2]; };
+  // issue the global loads of pair/tile pq (no LDS access): can be overlapped with compute
+  static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegs& X) {
+    const i32 lane = B::opaque(B::lane());
+    const bool fast = a.fast;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        if constexpr (GEO::OUTER) {
+          const int b = 2 * pq + pl;
+          const bool ok = b < a.B;
+          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+          X.v[i][pl] = gload8((const uint16_t*)a.u + ro, row * GEO::Mi + m, a.L, fast, ok);
+        } else {
+          i32 b = (row + pq * GEO::G) * 2 + pl;
+          X.v[i][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, m, fast, b < a.B);
+        }
+      }
+    }
+  }
+  // (x) pregate, swizzle, write to E
+  static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegs& X) {
     const i32 lane = B::opaque(B::lane());
     const bool fast = a.fast;
 #pragma unroll
@@ -261,28 +282,19 @@ struct Body {
       i32 off = pair_off(row, m, &sw) + un.eb;
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
-        U4 v;
-        if constexpr (GEO::OUTER) {
-          const int b = 2 * pq + pl;
-          const bool ok = b < a.B;
-          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
-          i32 n = row * GEO::Mi + m;
-          // rows entirely beyond L are never read (phase A substitutes zeros): skip them
-          v = gload8((const uint16_t*)a.u + ro, n, a.L, fast, ok);
-          if (a.pregate) {
-            U4 g = gload8((const uint16_t*)a.pregate + ro, n, a.L, fast, ok);
-            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
+        U4 v = X.v[i][pl];
+        if (a.pregate) {
+          U4 g;
+          if constexpr (GEO::OUTER) {
+            const int b = 2 * pq + pl;
+            const bool ok = b < a.B;
+            const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+            g = gload8((const uint16_t*)a.pregate + ro, row * GEO::Mi + m, a.L, fast, ok);
+          } else {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            g = gload8_rows((const uint16_t*)a.pregate, b, h, a, m, fast, b < a.B);
           }
-        } else {
-          // row = pair index inside the tile; batch row differs per lane -> per-lane element offset
-          i32 b = (row + pq * GEO::G) * 2 + pl;
-          pred ok = b < a.B;
-          i32 n = m;
-          v = gload8_rows((const uint16_t*)a.u, b, h, a, n, fast, ok);
-          if (a.pregate) {
-            U4 g = gload8_rows((const uint16_t*)a.pregate, b, h, a, n, fast, ok);
-            v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
-          }
+          v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
         }
         U4 o;
         o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
@@ -290,6 +302,11 @@ struct Body {
         B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
       }
     }
+  }
+  static FFC_FN void rows_in(const ConvArgs& a, int h, int pq, Unit un) {
+    RowRegs X;
+    rows_load(a, h, pq, un, X);
+    rows_store(a, h, pq, un, X);
   }
   // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
   // 32 bits in 16-byte units (launcher checks the tensor size).
@@ -417,8 +434,8 @@ struct Body {
           xpose2(rawr[ms], tp, th, op.r[ms]);
           xpose2(rawi[ms], tp, th, op.i[ms]);
         }
-        f32 re[16], im[16];
-        zero(re); zero(im);
+        A16 re, im;
+        re = B::a16_zero(); im = B::a16_zero();
         cmm<!FWD, false>(re, im, op, F1, ms_lim);
         if (FWD) {
           if (tp + th > 0) cmul_small(tw, GEO::L_DELTA);
@@ -494,16 +511,16 @@ struct Body {
   }
 
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
-  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, f32 (&re)[16], f32 (&im)[16]) {
+  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
     Op op;
     load_tile_op(tau, op, un);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
-    zero(re); zero(im);
+    re = B::a16_zero(); im = B::a16_zero();
     cmm<false, true>(re, im, op, R.F2);
     cmul(re, im, R.tw);
     to_op(re, im, op);
     // stage b: contract n3 (B-form) -> [V'=(sV,k3) regs][U' lanes]
-    zero(re); zero(im);
+    re = B::a16_zero(); im = B::a16_zero();
     if constexpr (GEO::N3 != GEO::N2) {
       Mat F3;
       lds_mat(F3, GEO::L_F3);
@@ -513,14 +530,13 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  static FFC_FN void tile_inv(const uint8_t* tab, const PlanTabs& t, int tau, const InnerRegs& R, Unit un,
-                              f32 (&re)[16], f32 (&im)[16]) {
+  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     Op op;
     to_op(re, im, op);
     // inverse stage b: contract k3 (A-form, conj) -> [U' regs][V''=(sV,n3) lanes]
-    zero(re); zero(im);
+    re = B::a16_zero(); im = B::a16_zero();
     if constexpr (GEO::N3 != GEO::N2) {
       Mat F3;
       lds_mat(F3, GEO::L_F3);
@@ -537,33 +553,22 @@ struct Body {
     }
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]
-    zero(re); zero(im);
+    re = B::a16_zero(); im = B::a16_zero();
     cmm<true, true>(re, im, op, R.F2);
-    // outer inverse twiddle W_N^{-(n2*N3+n3)*k1}
+    // outer inverse twiddle s_inv * W_N^{-(n2*N3+n3)*k1}, generated on the fly (v_sin/v_cos take
+    // revolutions; the integer phase m*k1 mod N is exact), so no table traffic in the tile loop
     if constexpr (GEO::OUTER) {
-      const uint8_t* pa = tab + t.oi_a + (int64_t)tau * (32 * GEO::SV * 8);
-      const uint8_t* pb = tab + t.oi_b + (int64_t)tau * (GEO::SU * 2 * 16 * 8);
-      f32 are[GEO::SV], aim[GEO::SV];
+      const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
 #pragma unroll
-      for (int s = 0; s < GEO::SV; s++) {
-        U2 v = B::g_r64(pa, c * GEO::SV + s, B::ptrue());
-        are[s] = B::as_f32(v.x); aim[s] = B::as_f32(v.y);
-      }
-      i32 bidx = ((c / GEO::N2) * 2 + hi) * 8;   // in 16-byte units (2 complex each)
-#pragma unroll
-      for (int rr = 0; rr < 8; rr++) {
-        U4 v = B::g_r128(pb, bidx + rr);
-        f32 br[2] = {B::as_f32(v.x), B::as_f32(v.z)}, bi[2] = {B::as_f32(v.y), B::as_f32(v.w)};
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-          int r = 2 * rr + q;
-          int s = (GEO::SV == 1) ? 0 : (r >> 3);
-          f32 tr = are[s] * br[q] - aim[s] * bi[q];
-          f32 ti = are[s] * bi[q] + aim[s] * br[q];
-          f32 x = re[r], y = im[r];
-          re[r] = x * tr - y * ti;
-          im[r] = x * ti + y * tr;
-        }
+      for (int r = 0; r < 16; r++) {
+        i32 V = hi * 4 + ((r & 3) + 8 * (r >> 2));
+        i32 k1 = sUl * GEO::SV + V / GEO::N3 + tau * GEO::G;
+        i32 ph = B::mul24(mlane + V % GEO::N3, k1) & (GEO::N - 1);
+        f32 x = B::i2f(ph) * (1.0f / (float)GEO::N);
+        f32 tr = B::cos_rev(x) * s_inv, ti = B::sin_rev(x) * s_inv;   // conj(W^{m k1}) = cos + i sin
+        f32 xr = re[r], xi = im[r];
+        re[r] = xr * tr - xi * ti;
+        im[r] = xr * ti + xi * tr;
       }
     }
     // write back in place: lane <-> (sU,n2), regs <-> (sV,n3); r&3 = 4 consecutive n3
@@ -584,31 +589,32 @@ struct Body {
     }
   }
 
-  static FFC_FN void inner_tile(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
+  struct KfRegs { U4 v[4]; };
+  static FFC_FN void load_kf(const ConvArgs& a, int h, int tau, KfRegs& k) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
-    f32 re[16], im[16];
+    const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+  }
+  static FFC_FN void inner_tile(const ConvArgs& a, int tau, const InnerRegs& R, Unit un, const KfRegs& kf) {
+    A16 re, im;
     tile_fwd(tau, R, un, re, im);
     // (x) k_f
-    {
-      const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
 #pragma unroll
-      for (int rq = 0; rq < 4; rq++) {
-        i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c);
-        U4 v = B::g_r128(kfh, idx);
-        u32 wv[4] = {v.x, v.y, v.z, v.w};
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
-          if (a.conj_kf) ki = B::fconst(0.f) - ki;
-          int r = 4 * rq + q;
-          f32 x = re[r], y = im[r];
-          re[r] = x * kr - y * ki;
-          im[r] = x * ki + y * kr;
-        }
+      for (int q = 0; q < 4; q++) {
+        f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
+        if (a.conj_kf) ki = B::fconst(0.f) - ki;
+        int r = 4 * rq + q;
+        f32 x = re[r], y = im[r];
+        re[r] = x * kr - y * ki;
+        im[r] = x * ki + y * kr;
       }
     }
-    tile_inv(a.tab, a.t, tau, R, un, re, im);
+    tile_inv(a.s_inv, tau, R, un, re, im);
   }
 
   // ------------------------------------------------------------------ workgroup entry: conv
@@ -625,13 +631,21 @@ struct Body {
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+      // PREFETCH: the next pair's rows are loaded into registers while phase C of the current pair runs
+      // (64 VGPRs live across phase C; enabled only where the register budget allows it)
+      constexpr bool PREFETCH = false;
+      RowRegs X;
+      if (PREFETCH && p0 + u < p1) rows_load(a, h, p0 + u, un, X);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
+        KfRegs kf0;
         if (act) {
-          rows_in(a, h, p, un);
+          if (!PREFETCH) rows_load(a, h, p, un, X);
+          rows_store(a, h, p, un, X);
           B::lds_fence();
+          load_kf(a, h, un.wq * GEO::TPW, kf0);        // in flight across phase A and the barrier
           if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) outer_stage<true, true>(a.L, un);
           else outer_stage<true, false>(a.L, un);
         }
@@ -639,10 +653,18 @@ struct Body {
         if (act) {
           InnerRegs R;
           load_inner(R);
-#pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) inner_tile(a, h, un.wq * GEO::TPW + tt, R, un);
+          KfRegs kf1;
+          load_kf(a, h, un.wq * GEO::TPW + 1, kf1);
+          inner_tile(a, un.wq * GEO::TPW + 0, R, un, kf0);
+          load_kf(a, h, un.wq * GEO::TPW + 2, kf0);
+          inner_tile(a, un.wq * GEO::TPW + 1, R, un, kf1);
+          load_kf(a, h, un.wq * GEO::TPW + 3, kf1);
+          inner_tile(a, un.wq * GEO::TPW + 2, R, un, kf0);
+          inner_tile(a, un.wq * GEO::TPW + 3, R, un, kf1);
         }
         B::barrier();
+        const int pn = p + GEO::UPW;
+        if (PREFETCH && pn < p1) rows_load(a, h, pn, un, X);
         if (act) {
           outer_stage<false, false>(a.L, un);
           B::lds_fence();
@@ -660,9 +682,11 @@ struct Body {
         const int q = q0 + it * GEO::UPW + u;
         const bool act = q < q1;
         if (act) {
+          KfRegs kf;
+          load_kf(a, h, 0, kf);
           rows_in(a, h, q, un);
           B::lds_fence();
-          inner_tile(a, h, 0, R, un);
+          inner_tile(a, 0, R, un, kf);
           B::lds_fence();
           rows_out(a, h, q, un);
         }

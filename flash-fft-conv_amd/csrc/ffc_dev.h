@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -33,7 +34,11 @@ struct DevB {
   using pred = bool;
   struct U2 { u32 x, y; };
   struct U4 { u32 x, y, z, w; };
+  using A16 = f32x16;   // 16 consecutive VGPRs/AGPRs: the MFMA accumulator tuple
+  using W4 = u32x4v;    // 4 consecutive VGPRs: one MFMA A/B operand
   static constexpr bool HAS_TR = true;
+  static FFC_FN A16 a16_zero() { A16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
+  static FFC_FN W4 w4(u32 a, u32 b, u32 c, u32 e) { W4 v = {a, b, c, e}; return v; }
 
   static FFC_FN i32 lane() { return (int)(threadIdx.x & 63); }
   static FFC_FN int wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
@@ -59,6 +64,7 @@ struct DevB {
   }
   static FFC_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   static FFC_FN u32 uconst(uint32_t c) { return c; }
+  static FFC_FN i32 mul24(i32 a, i32 b) { return __mul24(a, b); }
   static FFC_FN f32 i2f(i32 a) { return (float)a; }
   static FFC_FN f32 cos_rev(f32 x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: argument in revolutions
   static FFC_FN f32 sin_rev(f32 x) { return __builtin_amdgcn_sinf(x); }
@@ -102,17 +108,11 @@ struct DevB {
     if (p) ((uint4*)base)[o16] = make_uint4(v.x, v.y, v.z, v.w);
   }
   template <int DT>
-  static FFC_FN void mfma(f32 (&acc)[16], const u32 (&a)[4], const u32 (&b)[4]) {
-    f32x16 c;
-#pragma unroll
-    for (int i = 0; i < 16; i++) c[i] = acc[i];
-    u32x4v av = {a[0], a[1], a[2], a[3]}, bv = {b[0], b[1], b[2], b[3]};
+  static FFC_FN void mfma(A16& acc, const W4& a, const W4& b) {
     if (DT == DT_BF16)
-      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     else
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), c, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = c[i];
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
   }
   template <int DT>
   static FFC_FN u32 pack(f32 lo, f32 hi) {
@@ -194,7 +194,9 @@ static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* n
   int upw = 8 / p->hp.NW;                       // units a workgroup processes per iteration
   int pairs_per_iter = outer ? upw : upw * p->hp.G;
   int wg_per_cu = outer ? 1 : 2;
-  int target = p->num_cu * wg_per_cu * 2;
+  int mult = 2;
+  if (const char* e = getenv("FFC_WG_MULT")) mult = atoi(e) > 0 ? atoi(e) : 2;   // tuning knob
+  int target = p->num_cu * wg_per_cu * mult;
   int iters_total = (npair + pairs_per_iter - 1) / pairs_per_iter;
   int nc = (target + H - 1) / H;
   if (nc > iters_total) nc = iters_total;

@@ -16,14 +16,12 @@ __global__ void kf_pack_kernel(const float2* __restrict__ src, const int32_t* __
 
 __global__ void selftest_kernel(const uint32_t* in, uint32_t* out) {
   int l = threadIdx.x;
-  uint32_t a[4], b[4];
+  DevB::W4 a, b;
   for (int i = 0; i < 4; i++) { a[i] = in[l * 8 + i]; b[i] = in[l * 8 + 4 + i]; }
-  float acc[16];
-  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  DevB::A16 acc = DevB::a16_zero();
   DevB::mfma<DT_BF16>(acc, a, b);
   for (int i = 0; i < 16; i++) out[l * 40 + i] = DevB::as_u32(acc[i]);
-  float acc2[16];
-  for (int i = 0; i < 16; i++) acc2[i] = 0.f;
+  DevB::A16 acc2 = DevB::a16_zero();
   DevB::mfma<DT_F16>(acc2, a, b);
   for (int i = 0; i < 16; i++) out[l * 40 + 16 + i] = DevB::as_u32(acc2[i]);
   DevB::lds_w64(l * 8, DevB::U2{a[0], a[1]});

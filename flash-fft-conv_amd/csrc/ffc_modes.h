@@ -38,6 +38,7 @@ struct DkArgs {
   PlanTabs t;
   int H, Lk, nslab;
   float scale;         // 1 / s_fwd  (W carries s_fwd^2, the inverse applies 1/(N s_fwd))
+  float s_inv;         // plan's 1/(N*s_fwd) (applied inside tile_inv for fused sizes >= 4096)
   void* outpair;       // optional complex output instead of dk: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;
 };
@@ -51,6 +52,8 @@ struct Modes : Body<B, GEO, DT> {
   using pred = typename B::pred;
   using U2 = typename B::U2;
   using U4 = typename B::U4;
+  using A16 = typename B::A16;
+  using W4 = typename B::W4;
   using Unit = typename BD::Unit;
   using Op = typename BD::Op;
   using InnerRegs = typename BD::InnerRegs;
@@ -93,7 +96,7 @@ struct Modes : Body<B, GEO, DT> {
       B::lds_w128(off + GEO::PLANE, z, B::ptrue());
     }
   }
-  static FFC_FN void kf_store(const KfArgs& a, int unit_id, int tau, const f32 (&re)[16], const f32 (&im)[16]) {
+  static FFC_FN void kf_store(const KfArgs& a, int unit_id, int tau, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -154,7 +157,7 @@ struct Modes : Body<B, GEO, DT> {
       if (act) {
 #pragma unroll 1
         for (int tt = 0; tt < GEO::TPW; tt++) {
-          f32 re[16], im[16];
+          A16 re, im;
           BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
           kf_store(a, unit_id, un.wq * GEO::TPW + tt, re, im);
         }
@@ -163,7 +166,7 @@ struct Modes : Body<B, GEO, DT> {
       if (act) {
         k_rows_in(a, unit_id, un);
         B::lds_fence();
-        f32 re[16], im[16];
+        A16 re, im;
         BD::tile_fwd(0, R, un, re, im);
         kf_store(a, unit_id, 0, re, im);
       }
@@ -171,7 +174,7 @@ struct Modes : Body<B, GEO, DT> {
   }
 
   // ------------------------------------------------------------------ dk_f accumulation
-  static FFC_FN void w_accum(float* slab, int tau, bool first, const Op& zv, const f32 (&re)[16], const f32 (&im)[16]) {
+  static FFC_FN void w_accum(float* slab, int tau, bool first, const Op& zv, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -247,7 +250,7 @@ struct Modes : Body<B, GEO, DT> {
           BD::load_inner(R);
 #pragma unroll
           for (int tt = 0; tt < GEO::TPW; tt++) {
-            f32 re[16], im[16];
+            A16 re, im;
             BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
             BD::to_op(re, im, zv[tt]);
           }
@@ -264,7 +267,7 @@ struct Modes : Body<B, GEO, DT> {
           BD::load_inner(R);
 #pragma unroll
           for (int tt = 0; tt < GEO::TPW; tt++) {
-            f32 re[16], im[16];
+            A16 re, im;
             BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
             w_accum(slab, un.wq * GEO::TPW + tt, it == 0, zv[tt], re, im);
           }
@@ -278,14 +281,14 @@ struct Modes : Body<B, GEO, DT> {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
       BD::load_inner(R);
-      f32 wre[16], wim[16];
-      BD::zero(wre); BD::zero(wim);
+      A16 wre, wim;
+      wre = B::a16_zero(); wim = B::a16_zero();
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int q = q0 + it * GEO::UPW + u;
         if (q < q1) {
           Op zv;
-          f32 re[16], im[16];
+          A16 re, im;
           BD::rows_in(av, h, q, un);
           B::lds_fence();
           BD::tile_fwd(0, R, un, re, im);
@@ -308,7 +311,7 @@ struct Modes : Body<B, GEO, DT> {
       store_w(slab, wre, wim);
     }
   }
-  static FFC_FN void store_w(float* slab, const f32 (&re)[16], const f32 (&im)[16]) {
+  static FFC_FN void store_w(float* slab, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -323,11 +326,11 @@ struct Modes : Body<B, GEO, DT> {
   }
 
   // ------------------------------------------------------------------ dk_f -> dk
-  static FFC_FN void w_load(const DkArgs& a, int unit_id, int tau, f32 (&re)[16], f32 (&im)[16]) {
+  static FFC_FN void w_load(const DkArgs& a, int unit_id, int tau, A16& re, A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const int64_t slab_stride = (int64_t)a.H * (GEO::NT * 2048);   // floats
-    BD::zero(re); BD::zero(im);
+    re = B::a16_zero(); im = B::a16_zero();
 #pragma unroll 1
     for (int s = 0; s < a.nslab; s++) {
       const float* sl = a.ws + s * slab_stride;
@@ -410,9 +413,9 @@ struct Modes : Body<B, GEO, DT> {
       if (act) {
 #pragma unroll 1
         for (int tt = 0; tt < GEO::TPW; tt++) {
-          f32 re[16], im[16];
+          A16 re, im;
           w_load(a, unit_id, un.wq * GEO::TPW + tt, re, im);
-          BD::tile_inv(a.tab, a.t, un.wq * GEO::TPW + tt, R, un, re, im);
+          BD::tile_inv(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im);
         }
       }
       B::barrier();
@@ -429,9 +432,9 @@ struct Modes : Body<B, GEO, DT> {
       }
     } else {
       if (act) {
-        f32 re[16], im[16];
+        A16 re, im;
         w_load(a, unit_id, 0, re, im);
-        BD::tile_inv(a.tab, a.t, 0, R, un, re, im);
+        BD::tile_inv(a.s_inv, 0, R, un, re, im);
         B::lds_fence();
         dk_rows_out(a, unit_id, un);
       }

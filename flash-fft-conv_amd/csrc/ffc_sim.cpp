@@ -64,6 +64,10 @@ struct SimB {
   using pred = Vec<bool>;
   struct U2 { u32 x, y; };
   struct U4 { u32 x, y, z, w; };
+  struct A16 { f32 v[16]; f32& operator[](int i) { return v[i]; } const f32& operator[](int i) const { return v[i]; } };
+  struct W4 { u32 v[4]; u32& operator[](int i) { return v[i]; } const u32& operator[](int i) const { return v[i]; } };
+  static A16 a16_zero() { A16 z; for (int i = 0; i < 16; i++) z.v[i] = f32(0.f); return z; }
+  static W4 w4(const u32& a, const u32& b, const u32& c, const u32& e) { W4 v; v.v[0] = a; v.v[1] = b; v.v[2] = c; v.v[3] = e; return v; }
   static bool HAS_TR;
 
   static i32 lane() { i32 r; for (int i = 0; i < 64; i++) r.v[i] = i; return r; }
@@ -127,6 +131,7 @@ struct SimB {
     return r;
   }
   static void lds_fence() {}
+  static i32 mul24(const i32& a, const i32& b) { return a * b; }
   static f32 i2f(const i32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)a.v[i]; return r; }
   static f32 cos_rev(const f32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)cos(6.283185307179586 * (double)a.v[i]); return r; }
   static f32 sin_rev(const f32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)sin(6.283185307179586 * (double)a.v[i]); return r; }
@@ -189,7 +194,7 @@ struct SimB {
   // D[i][j] += sum_k A[i][k] B[k][j];  A lane l: A[l&31][8*(l>>5)+e];  B lane l: B[8*(l>>5)+e][l&31];
   // D lane l reg r: D[acc_row(r, l>>5)][l&31].
   template <int DT>
-  static void mfma(f32 (&acc)[16], const u32 (&a)[4], const u32 (&b)[4]) {
+  static void mfma(A16& acc, const W4& a, const W4& b) {
     float A[32][16], Bm[16][32];
     for (int l = 0; l < 64; l++)
       for (int e = 0; e < 8; e++) {
@@ -294,10 +299,9 @@ void ffcsim_force_slow_io(int on) { g_force_slow = on != 0; }
 int ffcsim_selftest_primitives(const uint32_t* in, uint32_t* out) {
   run_wg(1, 1024, [&]() {
     using Bk = SimB;
-    Bk::u32 a[4], b[4];
+    Bk::W4 a, b;
     for (int i = 0; i < 4; i++) for (int l = 0; l < 64; l++) { a[i].v[l] = in[l * 8 + i]; b[i].v[l] = in[l * 8 + 4 + i]; }
-    Bk::f32 acc[16], acc2[16];
-    for (int i = 0; i < 16; i++) { acc[i] = Bk::f32(0.f); acc2[i] = Bk::f32(0.f); }
+    Bk::A16 acc = Bk::a16_zero(), acc2 = Bk::a16_zero();
     Bk::mfma<DT_BF16>(acc, a, b);
     Bk::mfma<DT_F16>(acc2, a, b);
     Bk::i32 lane = Bk::lane();
@@ -337,7 +341,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
   a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
-  a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf;
+  a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv;
   a.fast = (L % 8 == 0) && !g_force_slow;
   return dispatch<ConvRun>(N, dtype, a);
 }
@@ -411,7 +415,7 @@ int ffcsim_kernel_ifft_grad_c(int N, const float* ws, int nslab, int H, void* ou
   HostPlan p;
   if (!build_plan(N, DT_BF16, &p)) return -1;
   DkArgs a{};
-  a.ws = ws; a.outpair = outpair; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.nslab = nslab; a.scale = scale; a.fast = 1;
+  a.ws = ws; a.outpair = outpair; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.nslab = nslab; a.scale = scale; a.s_inv = (float)p.s_inv; a.fast = 1;
   return dispatch<DkRun>(N, DT_BF16, a);
 }
 
@@ -422,7 +426,8 @@ int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H,
   if (!build_plan(N, dtype, &p)) return -1;
   DkArgs a{};
   a.ws = ws; a.dk = dk; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk; a.nslab = nslab;
-  a.scale = (float)(1.0 / p.s_fwd);   // tile_inv already applies s_inv = 1/(N s_fwd) a.fast = (Lk % 4 == 0) && !g_force_slow;
+  a.scale = (float)(1.0 / p.s_fwd); a.s_inv = (float)p.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
+  a.fast = (Lk % 4 == 0) && !g_force_slow;
   return dispatch<DkRun>(N, dtype, a);
 }
 
