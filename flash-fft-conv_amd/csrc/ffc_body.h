@@ -653,14 +653,13 @@ struct Body {
         if (act) {
           InnerRegs R;
           load_inner(R);
-          KfRegs kf1;
-          load_kf(a, h, un.wq * GEO::TPW + 1, kf1);
-          inner_tile(a, un.wq * GEO::TPW + 0, R, un, kf0);
-          load_kf(a, h, un.wq * GEO::TPW + 2, kf0);
-          inner_tile(a, un.wq * GEO::TPW + 1, R, un, kf1);
-          load_kf(a, h, un.wq * GEO::TPW + 3, kf1);
-          inner_tile(a, un.wq * GEO::TPW + 2, R, un, kf0);
-          inner_tile(a, un.wq * GEO::TPW + 3, R, un, kf1);
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            KfRegs kfn;
+            if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);   // next tile's k_f in flight
+            inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
+            kf0 = kfn;
+          }
         }
         B::barrier();
         const int pn = p + GEO::UPW;

@@ -174,7 +174,15 @@ struct Modes : Body<B, GEO, DT> {
   }
 
   // ------------------------------------------------------------------ dk_f accumulation
-  static FFC_FN void w_accum(float* slab, int tau, bool first, const Op& zv, const A16& re, const A16& im) {
+  struct ZReg { u32 r[8], i[8]; };   // a spectrum tile as packed dtype pairs (plain dwords: no register-tuple constraint)
+  static FFC_FN void z_pack(const A16& re, const A16& im, ZReg& z) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      z.r[q] = B::template pack<DT>(re[2 * q], re[2 * q + 1]);
+      z.i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
+    }
+  }
+  static FFC_FN void w_accum(float* slab, int tau, bool first, const ZReg& zv, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -184,7 +192,7 @@ struct Modes : Body<B, GEO, DT> {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int r = 4 * rq + q;
-        u32 pr = zv.r[r >> 3][(r & 7) >> 1], pi = zv.i[r >> 3][(r & 7) >> 1];
+        u32 pr = zv.r[r >> 1], pi = zv.i[r >> 1];
         f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
         f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
         // Zd * conj(Zv)
@@ -245,14 +253,14 @@ struct Modes : Body<B, GEO, DT> {
           else BD::template outer_stage<true, false>(a.L, un);
         }
         B::barrier();
-        Op zv[GEO::TPW];
+        ZReg zv[GEO::TPW];
         if (act) {
           BD::load_inner(R);
 #pragma unroll
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
             BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-            BD::to_op(re, im, zv[tt]);
+            z_pack(re, im, zv[tt]);
           }
         }
         B::barrier();
@@ -287,19 +295,19 @@ struct Modes : Body<B, GEO, DT> {
       for (int it = 0; it < iters; it++) {
         const int q = q0 + it * GEO::UPW + u;
         if (q < q1) {
-          Op zv;
+          ZReg zv;
           A16 re, im;
           BD::rows_in(av, h, q, un);
           B::lds_fence();
           BD::tile_fwd(0, R, un, re, im);
-          BD::to_op(re, im, zv);
+          z_pack(re, im, zv);
           B::lds_fence();
           BD::rows_in(ad, h, q, un);
           B::lds_fence();
           BD::tile_fwd(0, R, un, re, im);
 #pragma unroll
           for (int r = 0; r < 16; r++) {
-            u32 pr = zv.r[r >> 3][(r & 7) >> 1], pi = zv.i[r >> 3][(r & 7) >> 1];
+            u32 pr = zv.r[r >> 1], pi = zv.i[r >> 1];
             f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
             f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
             wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
