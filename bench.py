@@ -132,12 +132,14 @@ def main():
     lib = _lib.lib()
     ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=dev)
     dk = torch.empty(H, L, dtype=torch.float32, device=dev)
+    dk_du = torch.empty_like(ud)
     sp = _lib.stream_ptr
     kt = {
         "kfft": time_kernel(lambda: C._kernel_fft(plan, kd)),
         "conv_fwd": time_kernel(lambda: C._conv(plan, ud, kf, None, None, False)),
         "conv_dx": time_kernel(lambda: C._conv(plan, dout, kf, None, None, True)),
-        "dkf": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(ud), None, None, _lib.ptr(ws), B, H, L, sp()), "dkf")),
+        "bwd_fused": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(ud), _lib.ptr(kf), None, None, _lib.ptr(dk_du), None, _lib.ptr(ws), B, H, L, sp()), "bwd")),
+        "dkf_only": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(ud), None, None, _lib.ptr(ws), B, H, L, sp()), "dkf")),
         "dk_ifft": time_kernel(lambda: _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, L, _lib.ptr(dk), sp()), "dk")),
     }
     if rank != 0:

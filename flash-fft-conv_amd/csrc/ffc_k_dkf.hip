@@ -20,6 +20,24 @@ struct DkfLaunch {
   }
 };
 
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel(DkfArgs d) {
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevB, GEO, DT>::bwd(d, h, chunk);
+}
+template <class GEO, int DT>
+struct BwdLaunch {
+  static int run(const DkfArgs& d, hipStream_t st) {
+    static int rc = ffc_set_lds(bwd_kernel<GEO, DT>, GEO::LDS_BYTES);
+    if (rc) return rc;
+    int hpad = (d.c.H + 7) & ~7;
+    hipLaunchKernelGGL((bwd_kernel<GEO, DT>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_kernel launch: ") + hipGetErrorString(e));
+  }
+};
+
 extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t H) {
   if (!p) return 0;
   int nchunk, ppc;
@@ -42,4 +60,23 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   d.dout = dout; d.ws = (float*)ws;
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
+}
+
+// Fused backward: du = pregate * corr(dout*postgate, k), dpre = u * corr(...) (nullable, gated only) and the
+// dk_f partial sums in `ws` (same layout as ffc_conv_bwd_dkf; finish with ffc_kernel_ifft_grad).
+extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                            const void* postgate, void* du, void* dpre, void* ws, int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
+  if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
+  if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
+  if ((uintptr_t)kf & 15) return ffc_fail("k_f must be 16-byte aligned");
+  if (B * H * L >= ((int64_t)1 << 31)) return ffc_fail("tensor too large (>= 2^31 elements)");
+  DkfArgs d{};
+  ConvArgs& a = d.c;
+  a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv;
+  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
+  ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre;
+  return ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
 }

@@ -29,6 +29,10 @@ struct DkfArgs {
   ConvArgs c;          // u / pregate / postgate as in the forward; c.y unused
   const void* dout;
   float* ws;           // [nchunk*UPW][H][NT*1024][2] fp32 partial sums (internal order)
+  // fused backward (Modes::bwd) only: c.kf = k_f, du = pregate * corr(dout*postgate, k),
+  // dpre = u * corr(dout*postgate, k) (nullable)
+  void* du;
+  void* dpre;
 };
 
 struct DkArgs {
@@ -319,6 +323,142 @@ struct Modes : Body<B, GEO, DT> {
       store_w(slab, wre, wim);
     }
   }
+  // ------------------------------------------------------------------ fused backward
+  // per pair: Z_v = FFT(u*pregate); Z_d = FFT(dout*postgate); W += Z_d conj(Z_v);
+  //           dv = iFFT(Z_d conj(k_f)); du = dv * pregate; dpre = dv * u.
+  // (reference: kernels_bf16/monarch_cuda_*_bwd_kernel_bf16.h compute the same three transforms)
+  static FFC_FN void kf_conj_mul(const typename BD::KfRegs& kf, A16& re, A16& im) {
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
+        int r = 4 * rq + q;
+        f32 x = re[r], y = im[r];
+        re[r] = x * kr + y * ki;
+        im[r] = y * kr - x * ki;
+      }
+    }
+  }
+  static FFC_FN void bwd(const DkfArgs& d, int h, int chunk) {
+    const ConvArgs& a = d.c;
+    BD::setup_tables(a.tab, a.t);
+    const int wv = B::wave();
+    Unit un;
+    un.wq = wv % GEO::NW;
+    const int u = wv / GEO::NW;
+    un.eb = u * GEO::EBYTES;
+    const int p0 = chunk * a.ppc;
+    int p1 = p0 + a.ppc;
+    if (p1 > a.npair) p1 = a.npair;
+    ConvArgs av = a;            // v = u * pregate
+    ConvArgs ad = a;            // dc = dout * postgate
+    ad.u = d.dout; ad.pregate = a.postgate;
+    ConvArgs ao = a;            // du = dv * pregate
+    ao.y = d.du; ao.postgate = a.pregate;
+    ConvArgs ap = a;            // dpre = dv * u
+    ap.y = d.dpre; ap.postgate = a.u;
+    float* slab = d.ws + ((int64_t)(chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    InnerRegs R;
+    if constexpr (GEO::OUTER) {
+      const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int p = p0 + it * GEO::UPW + u;
+        const bool act = p < p1;
+        if (act) {
+          BD::rows_in(av, h, p, un);
+          B::lds_fence();
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
+          else BD::template outer_stage<true, false>(a.L, un);
+        }
+        B::barrier();
+        ZReg zv[GEO::TPW];
+        if (act) {
+          BD::load_inner(R);
+#pragma unroll
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            A16 re, im;
+            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            z_pack(re, im, zv[tt]);
+          }
+        }
+        B::barrier();
+        if (act) {
+          BD::rows_in(ad, h, p, un);
+          B::lds_fence();
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
+          else BD::template outer_stage<true, false>(a.L, un);
+        }
+        B::barrier();
+        if (act) {
+          BD::load_inner(R);
+#pragma unroll
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            typename BD::KfRegs kf;
+            BD::load_kf(a, h, un.wq * GEO::TPW + tt, kf);
+            A16 re, im;
+            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            w_accum(slab, un.wq * GEO::TPW + tt, it == 0, zv[tt], re, im);
+            kf_conj_mul(kf, re, im);
+            BD::tile_inv(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im);
+          }
+        } else if (it == 0) {
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
+        }
+        B::barrier();
+        if (act) {
+          BD::template outer_stage<false, false>(a.L, un);
+          B::lds_fence();
+          BD::rows_out(ao, h, p, un);
+          if (d.dpre) BD::rows_out(ap, h, p, un);
+        }
+        // next iteration's rows_in touches only this wave's own columns, which it has finished reading
+      }
+    } else {
+      const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
+      const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
+      BD::load_inner(R);
+      A16 wre = B::a16_zero(), wim = B::a16_zero();
+#pragma unroll 1
+      for (int it = 0; it < iters; it++) {
+        const int q = q0 + it * GEO::UPW + u;
+        if (q < q1) {
+          ZReg zv;
+          A16 re, im;
+          typename BD::KfRegs kf;
+          BD::load_kf(a, h, 0, kf);
+          BD::rows_in(av, h, q, un);
+          B::lds_fence();
+          BD::tile_fwd(0, R, un, re, im);
+          z_pack(re, im, zv);
+          B::lds_fence();
+          BD::rows_in(ad, h, q, un);
+          B::lds_fence();
+          BD::tile_fwd(0, R, un, re, im);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            u32 pr = zv.r[r >> 1], pi = zv.i[r >> 1];
+            f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
+            f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
+            wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
+            wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
+          }
+          kf_conj_mul(kf, re, im);
+          B::lds_fence();
+          BD::tile_inv(a.s_inv, 0, R, un, re, im);
+          B::lds_fence();
+          BD::rows_out(ao, h, q, un);
+          if (d.dpre) BD::rows_out(ap, h, q, un);
+          B::lds_fence();
+        }
+      }
+      store_w(slab, wre, wim);
+    }
+  }
+
   static FFC_FN void store_w(float* slab, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;

@@ -277,6 +277,13 @@ template <class GEO, int DT> struct DkfRun {
         run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkf(d, h, c); });
   }
 };
+template <class GEO, int DT> struct BwdRun {
+  static void run(const DkfArgs& d) {
+    for (int h = 0; h < d.c.H; h++)
+      for (int c = 0; c < d.c.nchunk; c++)
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::bwd(d, h, c); });
+  }
+};
 template <class GEO, int DT> struct DkRun {
   static void run(const DkArgs& a) {
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
@@ -409,6 +416,27 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   d.dout = dout; d.ws = ws;
   int rc = dispatch<DkfRun>(N, dtype, d);
   return rc < 0 ? rc : a.nchunk * upw;   // number of slabs written
+}
+
+// fused backward: du (and dpre if non-null) + dk_f slabs; returns the number of slabs
+int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
+                    void* du, void* dpre, float* ws, int B, int H, int L, int nchunk) {
+  HostPlan p;
+  if (!build_plan(N, dtype, &p)) return -1;
+  DkfArgs d{};
+  ConvArgs& a = d.c;
+  a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
+  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_inv = (float)p.s_inv;
+  int upw = ffcsim_upw(N);
+  int per_iter = p.N1 > 1 ? upw : upw * p.G;
+  int iters_total = (a.npair + per_iter - 1) / per_iter;
+  if (nchunk > iters_total) nchunk = iters_total;
+  int ipc = (iters_total + nchunk - 1) / nchunk;
+  a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
+  a.fast = (L % 8 == 0) && !g_force_slow;
+  d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre;
+  int rc = dispatch<BwdRun>(N, dtype, d);
+  return rc < 0 ? rc : a.nchunk * upw;
 }
 
 int ffcsim_kernel_ifft_grad_c(int N, const float* ws, int nslab, int H, void* outpair, float scale) {

@@ -201,20 +201,19 @@ class _FlashFFTConvFn(torch.autograd.Function):
         plan = ctx.mod._get_plan(u.device)
         B, H, L = u.shape
         lib = _lib.lib()
-        # dk: fp32 accumulation of FFT(dout*postgate) * conj(FFT(u*pregate)) over the batch, then inverse
+        # one fused launch: du (and dpregate) + fp32 dk_f partial sums; then dk_f -> dk
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
-        _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(pregate), _lib.ptr(postgate),
-                                        _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_dkf")
+        du = torch.empty_like(u)
+        dpre = torch.empty_like(u) if ctx.gated else None
+        _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
+                                    _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd")
         dk = torch.empty(H, ctx.k_len, dtype=torch.float32, device=u.device)
         _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, ctx.k_len, _lib.ptr(dk), _lib.stream_ptr()),
                    "ffc_kernel_ifft_grad")
         dk = dk.to(ctx.k_dtype)
         if not ctx.gated:
-            du = _conv(plan, dout, kf, None, None, True)
             return du, dk, None, None, None
-        # gated: dv = corr(dout*postgate, k); du = dv*pregate; dpregate = dv*u; dpostgate = dout*conv(u*pregate)
-        du = _conv(plan, dout, kf, postgate, pregate, True)
-        dpre = _conv(plan, dout, kf, postgate, u, True)
+        # dpostgate = dout * conv(u*pregate, k): recompute the forward with dout as the output gate
         dpost = _conv(plan, u, kf, pregate, dout, False)
         return du, dk, None, dpre, dpost
 

@@ -51,6 +51,11 @@ int ffc_conv_fwd(const ffc_plan* plan, const void* u, const void* kf, const void
 int64_t ffc_dkf_workspace_bytes(const ffc_plan* plan, int64_t B, int64_t H);
 int ffc_conv_bwd_dkf(const ffc_plan* plan, const void* dout, const void* u, const void* pregate, const void* postgate,
                      void* ws, int64_t B, int64_t H, int64_t L, void* stream);
+/* Fused backward (one launch): du = pregate * corr(dout*postgate, k), dpre = u * corr(...) (nullable) and the
+ * dk_f partial sums in ws.  Covers monarch_conv_backward{,_r2r,_16_16_16,...} (monarch.cpp:27-32): three
+ * transforms per pair like the reference's bwd kernels, dk_f kept in fp32. */
+int ffc_conv_bwd(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
+                 const void* postgate, void* du, void* dpre, void* ws, int64_t B, int64_t H, int64_t L, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

@@ -152,3 +152,19 @@ class SimOps:
         rc = lib().ffcsim_kernel_ifft_grad_c(M, p(ws), self.nslab, hp, p(out), ctypes.c_float(scale))
         assert rc == 0, rc
         return out
+
+
+def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchunk=1):
+    """Fused backward on the simulator: returns (du bits, dpre bits or None, dk fp32)."""
+    B, H, L = u_bits.shape
+    nt, _, _, _ = plan_info(N, dtype)
+    upw = lib().ffcsim_upw(N)
+    ws = np.full(max(nchunk, 1) * upw * H * nt * 2048, np.nan, np.float32)
+    du = np.zeros_like(u_bits)
+    dpre = np.zeros_like(u_bits) if pre is not None else None
+    nslab = lib().ffcsim_conv_bwd(N, dtype, p(dout_bits), p(u_bits), p(kf_bits), p(pre), p(post), p(du), p(dpre), p(ws),
+                                  B, H, L, nchunk)
+    assert nslab > 0, nslab
+    dk = np.full((H, Lk), np.nan, np.float32)
+    assert lib().ffcsim_kernel_ifft_grad(N, dtype, p(ws), nslab, H, Lk, p(dk)) == 0
+    return du, dpre, dk

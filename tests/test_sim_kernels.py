@@ -143,3 +143,24 @@ def test_big_sizes_through_outer_levels(N, L, B, gated):
     dk = BG.dk_from_slabs(ops, N, ops.dkf(dt, M, xd, xu), xu.shape[0], H, L)
     _, dkref = O.ref_grads(q(u, dt), k, q(d, dt), N)
     assert rel(dk, dkref) < 1.5e-2
+
+
+@pytest.mark.parametrize("N,L,B,H,nch,gated", [(256, 128, 9, 2, 1, True), (1024, 1024, 3, 2, 1, False), (4096, 2048, 5, 2, 2, True),
+                                               (16384, 8192, 3, 1, 1, False), (32768, 16384, 3, 2, 2, True)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_fused_backward(N, L, B, H, nch, gated, dt):
+    """Modes::bwd: du (+ dpregate) and the dk_f slabs from one pass (3 transforms per pair)."""
+    rng = np.random.default_rng(N + L)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    du, dpre, dk = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, L, pre, post, nch)
+    if gated:
+        r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt))
+        assert rel(S.from_bits(dpre, dt), r[2]) < TOL[dt]
+    else:
+        r = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(S.from_bits(du, dt), r[0]) < TOL[dt]
+    assert rel(dk, r[1]) < 1.5 * TOL[0]
