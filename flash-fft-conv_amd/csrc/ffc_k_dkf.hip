@@ -6,7 +6,7 @@ template <class GEO, int DT>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::dkf(d, h, chunk);
+  Modes<DevB, GEO, DT>::dkf(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct DkfLaunch {
@@ -24,7 +24,7 @@ template <class GEO, int DT>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::bwd(d, h, chunk);
+  Modes<DevB, GEO, DT>::bwd(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct BwdLaunch {
@@ -43,7 +43,15 @@ extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   int upw = 8 / p->hp.NW;
-  return (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
+  int64_t slabs = (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
+  // + spectrum scratch: one N-point dtype-complex slot per (workgroup, unit) of the grid
+  int64_t hpad = (H + 7) & ~(int64_t)7;
+  int64_t zs = p->hp.N1 > 1 ? hpad * nchunk * upw * (int64_t)p->hp.N * 4 : 0;
+  return slabs + zs;
+}
+static void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk) {
+  int upw = 8 / p->hp.NW;
+  return (uint8_t*)ws + (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
 }
 
 extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void* u, const void* pregate, const void* postgate,
@@ -58,7 +66,7 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
-  d.dout = dout; d.ws = (float*)ws;
+  d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
 }
 
@@ -77,6 +85,6 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
-  d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre;
+  d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
 }

@@ -33,6 +33,9 @@ struct DkfArgs {
   // dpre = u * corr(dout*postgate, k) (nullable)
   void* du;
   void* dpre;
+  // scratch for the first spectrum of a pair (dtype, internal order), one N-point slot per (workgroup, unit):
+  // written and read back by the same wave, so it only has to survive in L2 (fused sizes >= 4096)
+  void* zscratch;
 };
 
 struct DkArgs {
@@ -186,6 +189,53 @@ struct Modes : Body<B, GEO, DT> {
       z.i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
     }
   }
+  static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      U4 v;
+      v.x = B::template pack<DT>(re[4 * rq], im[4 * rq]);         v.y = B::template pack<DT>(re[4 * rq + 1], im[4 * rq + 1]);
+      v.z = B::template pack<DT>(re[4 * rq + 2], im[4 * rq + 2]); v.w = B::template pack<DT>(re[4 * rq + 3], im[4 * rq + 3]);
+      B::g_w128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
+    }
+  }
+  static FFC_FN void z_load(const void* zs, int tau, typename BD::KfRegs& z) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+  }
+  // W (+)= Zd * conj(Zv), Zv given as (re,im)-interleaved dtype pairs (KfRegs layout)
+  static FFC_FN void w_accum_z(float* slab, int tau, bool first, const typename BD::KfRegs& zv, const A16& re, const A16& im) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2;
+      u32 wv[4] = {zv.v[rq].x, zv.v[rq].y, zv.v[rq].z, zv.v[rq].w};
+      f32 wr[4], wi[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * rq + q;
+        f32 ur = B::template unpack_lo<DT>(wv[q]), ui = B::template unpack_hi<DT>(wv[q]);
+        wr[q] = re[r] * ur + im[r] * ui;
+        wi[q] = im[r] * ur - re[r] * ui;
+      }
+      if (!first) {
+        U4 o0 = B::g_r128(slab, idx), o1 = B::g_r128(slab, idx + 1);
+        wr[0] = wr[0] + B::as_f32(o0.x); wi[0] = wi[0] + B::as_f32(o0.y);
+        wr[1] = wr[1] + B::as_f32(o0.z); wi[1] = wi[1] + B::as_f32(o0.w);
+        wr[2] = wr[2] + B::as_f32(o1.x); wi[2] = wi[2] + B::as_f32(o1.y);
+        wr[3] = wr[3] + B::as_f32(o1.z); wi[3] = wi[3] + B::as_f32(o1.w);
+      }
+      U4 n0, n1;
+      n0.x = B::as_u32(wr[0]); n0.y = B::as_u32(wi[0]); n0.z = B::as_u32(wr[1]); n0.w = B::as_u32(wi[1]);
+      n1.x = B::as_u32(wr[2]); n1.y = B::as_u32(wi[2]); n1.z = B::as_u32(wr[3]); n1.w = B::as_u32(wi[3]);
+      B::g_w128(slab, idx, n0, B::ptrue());
+      B::g_w128(slab, idx + 1, n1, B::ptrue());
+    }
+  }
   static FFC_FN void w_accum(float* slab, int tau, bool first, const ZReg& zv, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
@@ -228,7 +278,7 @@ struct Modes : Body<B, GEO, DT> {
       B::g_w128(slab, idx + 1, z, B::ptrue());
     }
   }
-  static FFC_FN void dkf(const DkfArgs& d, int h, int chunk) {
+  static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear) {
     const ConvArgs& a = d.c;
     BD::setup_tables(a.tab, a.t);
     const int wv = B::wave();
@@ -246,6 +296,7 @@ struct Modes : Body<B, GEO, DT> {
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+      uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -257,14 +308,13 @@ struct Modes : Body<B, GEO, DT> {
           else BD::template outer_stage<true, false>(a.L, un);
         }
         B::barrier();
-        ZReg zv[GEO::TPW];
         if (act) {
           BD::load_inner(R);
-#pragma unroll
+#pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
             BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-            z_pack(re, im, zv[tt]);
+            z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
         B::barrier();
@@ -277,11 +327,14 @@ struct Modes : Body<B, GEO, DT> {
         B::barrier();
         if (act) {
           BD::load_inner(R);
-#pragma unroll
+#pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
+            const int tau = un.wq * GEO::TPW + tt;
+            typename BD::KfRegs zv;
+            z_load(zs, tau, zv);
             A16 re, im;
-            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-            w_accum(slab, un.wq * GEO::TPW + tt, it == 0, zv[tt], re, im);
+            BD::tile_fwd(tau, R, un, re, im);
+            w_accum_z(slab, tau, it == 0, zv, re, im);
           }
         } else if (it == 0) {
 #pragma unroll 1
@@ -341,7 +394,7 @@ struct Modes : Body<B, GEO, DT> {
       }
     }
   }
-  static FFC_FN void bwd(const DkfArgs& d, int h, int chunk) {
+  static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear) {
     const ConvArgs& a = d.c;
     BD::setup_tables(a.tab, a.t);
     const int wv = B::wave();
@@ -363,6 +416,7 @@ struct Modes : Body<B, GEO, DT> {
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+      uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -374,14 +428,13 @@ struct Modes : Body<B, GEO, DT> {
           else BD::template outer_stage<true, false>(a.L, un);
         }
         B::barrier();
-        ZReg zv[GEO::TPW];
         if (act) {
           BD::load_inner(R);
-#pragma unroll
+#pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
             BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-            z_pack(re, im, zv[tt]);
+            z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
         B::barrier();
@@ -394,15 +447,18 @@ struct Modes : Body<B, GEO, DT> {
         B::barrier();
         if (act) {
           BD::load_inner(R);
-#pragma unroll
+#pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
+            const int tau = un.wq * GEO::TPW + tt;
+            typename BD::KfRegs zv;
+            z_load(zs, tau, zv);
             typename BD::KfRegs kf;
-            BD::load_kf(a, h, un.wq * GEO::TPW + tt, kf);
+            BD::load_kf(a, h, tau, kf);
             A16 re, im;
-            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-            w_accum(slab, un.wq * GEO::TPW + tt, it == 0, zv[tt], re, im);
+            BD::tile_fwd(tau, R, un, re, im);
+            w_accum_z(slab, tau, it == 0, zv, re, im);
             kf_conj_mul(kf, re, im);
-            BD::tile_inv(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im);
+            BD::tile_inv(a.s_inv, tau, R, un, re, im);
           }
         } else if (it == 0) {
 #pragma unroll 1
@@ -415,7 +471,6 @@ struct Modes : Body<B, GEO, DT> {
           BD::rows_out(ao, h, p, un);
           if (d.dpre) BD::rows_out(ap, h, p, un);
         }
-        // next iteration's rows_in touches only this wave's own columns, which it has finished reading
       }
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -274,14 +274,14 @@ template <class GEO, int DT> struct DkfRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkf(d, h, c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c); });
   }
 };
 template <class GEO, int DT> struct BwdRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::bwd(d, h, c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c); });
   }
 };
 template <class GEO, int DT> struct DkRun {
@@ -414,6 +414,8 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
   d.dout = dout; d.ws = ws;
+  std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
+  d.zscratch = zs.data();
   int rc = dispatch<DkfRun>(N, dtype, d);
   return rc < 0 ? rc : a.nchunk * upw;   // number of slabs written
 }
@@ -435,6 +437,8 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre;
+  std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
+  d.zscratch = zs.data();
   int rc = dispatch<BwdRun>(N, dtype, d);
   return rc < 0 ? rc : a.nchunk * upw;
 }
