@@ -247,13 +247,16 @@ struct Body {
   static constexpr int CPR = GEO::OUTER ? 16 * GEO::S1 : GEO::Mi / 8;   // 16-B chunks per row per wave
   static constexpr int NCH = GEO::OUTER ? 8 : 2;                        // chunks per lane per plane
 
-  struct RowRegs { U4 v[NCH][2]; };
+  // NC = chunks per lane per plane actually moved: NCH, or NCH/2 when only E rows < 16 carry data
+  template <int NC> struct RowRegsT { U4 v[NC][2]; };
+  using RowRegs = RowRegsT<NCH>;
   // issue the global loads of pair/tile pq (no LDS access): can be overlapped with compute
-  static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegs& X) {
+  template <int NC>
+  static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
     const bool fast = a.fast;
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
+    for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;
       i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
 #pragma unroll
@@ -271,11 +274,12 @@ struct Body {
     }
   }
   // (x) pregate, swizzle, write to E
-  static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegs& X) {
+  template <int NC>
+  static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
     const bool fast = a.fast;
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
+    for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;
       i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
       pred sw;
@@ -341,11 +345,12 @@ struct Body {
     }
   }
 
+  template <int NC = NCH>
   static FFC_FN void rows_out(const ConvArgs& a, int h, int pq, Unit un) {
     const i32 lane = B::opaque(B::lane());
     const bool fast = a.fast;
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
+    for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;
       i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
       pred sw;
@@ -445,6 +450,7 @@ struct Body {
         for (int r = 0; r < 16; r++) {
           u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
           u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
+          if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
           if (th == 1) {
             const int c = (r & 3) + 8 * (r >> 2);
             const int s1 = c / GEO::N1, rwc = c % GEO::N1;
@@ -617,6 +623,51 @@ struct Body {
     tile_inv(a.s_inv, tau, R, un, re, im);
   }
 
+  // Job loop of the fused sizes.  HALF (32-point outer digit, L <= N/2): only E rows < 16 carry input and
+  // only result rows < 16 are stored, so half of the row traffic is skipped and the next pair's rows fit in
+  // 32 VGPRs: they are prefetched right after phase A and written to E after rows_out of the current pair.
+  template <bool HALF>
+  static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un) {
+    constexpr int NC = HALF ? NCH / 2 : NCH;
+    constexpr bool PREFETCH = HALF;
+    const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+    RowRegsT<NC> X;
+    if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+      const int p = p0 + it * GEO::UPW + u;
+      const bool act = p < p1;
+      KfRegs kf0;
+      if (act) {
+        if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
+        rows_store<NC>(a, h, p, un, X);
+        B::lds_fence();
+        load_kf(a, h, un.wq * GEO::TPW, kf0);        // in flight across phase A and the barrier
+        outer_stage<true, HALF>(a.L, un);
+      }
+      const int pn = p + GEO::UPW;
+      if (PREFETCH && pn < p1) rows_load<NC>(a, h, pn, un, X);   // lands while phases B/C run
+      B::barrier();
+      if (act) {
+        InnerRegs R;
+        load_inner(R);
+#pragma unroll 1
+        for (int tt = 0; tt < GEO::TPW; tt++) {
+          KfRegs kfn;
+          if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);   // next tile's k_f in flight
+          inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
+          kf0 = kfn;
+        }
+      }
+      B::barrier();
+      if (act) {
+        outer_stage<false, HALF>(a.L, un);
+        B::lds_fence();
+        rows_out<NC>(a, h, p, un);
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ workgroup entry: conv
   // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
@@ -630,46 +681,8 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
-      // PREFETCH: the next pair's rows are loaded into registers while phase C of the current pair runs
-      // (64 VGPRs live across phase C; enabled only where the register budget allows it)
-      constexpr bool PREFETCH = false;
-      RowRegs X;
-      if (PREFETCH && p0 + u < p1) rows_load(a, h, p0 + u, un, X);
-#pragma unroll 1
-      for (int it = 0; it < iters; it++) {
-        const int p = p0 + it * GEO::UPW + u;
-        const bool act = p < p1;
-        KfRegs kf0;
-        if (act) {
-          if (!PREFETCH) rows_load(a, h, p, un, X);
-          rows_store(a, h, p, un, X);
-          B::lds_fence();
-          load_kf(a, h, un.wq * GEO::TPW, kf0);        // in flight across phase A and the barrier
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) outer_stage<true, true>(a.L, un);
-          else outer_stage<true, false>(a.L, un);
-        }
-        B::barrier();
-        if (act) {
-          InnerRegs R;
-          load_inner(R);
-#pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) {
-            KfRegs kfn;
-            if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);   // next tile's k_f in flight
-            inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
-            kf0 = kfn;
-          }
-        }
-        B::barrier();
-        const int pn = p + GEO::UPW;
-        if (PREFETCH && pn < p1) rows_load(a, h, pn, un, X);
-        if (act) {
-          outer_stage<false, false>(a.L, un);
-          B::lds_fence();
-          rows_out(a, h, p, un);
-        }
-      }
+      if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) outer_jobs<true>(a, h, p0, p1, u, un);
+      else outer_jobs<false>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
