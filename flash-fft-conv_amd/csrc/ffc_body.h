@@ -39,6 +39,8 @@ struct ConvArgs {
   int conj_kf;           // 1: multiply by conj(k_f)  (input-gradient pass)
   int fast;              // 1: L % 8 == 0 and 16-byte aligned tensors -> 16-byte global accesses
   float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
+  int flags;             // bit0: prefetch the next pair's rows (HALF job loop)
+  unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
 template <class B, class GEO, int DT>
@@ -626,28 +628,34 @@ struct Body {
   // Job loop of the fused sizes.  HALF (32-point outer digit, L <= N/2): only E rows < 16 carry input and
   // only result rows < 16 are stored, so half of the row traffic is skipped and the next pair's rows fit in
   // 32 VGPRs: they are prefetched right after phase A and written to E after rows_out of the current pair.
-  template <bool HALF>
-  static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un) {
+  template <bool HALF, bool PROF = false>
+  static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
-    constexpr bool PREFETCH = HALF;
+    const bool PREFETCH = HALF && (a.flags & 1);
     const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
     RowRegsT<NC> X;
     if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
+    unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+#define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
       const int p = p0 + it * GEO::UPW + u;
       const bool act = p < p1;
       KfRegs kf0;
+      if (PROF) t0 = B::clock();
       if (act) {
         if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
         rows_store<NC>(a, h, p, un, X);
         B::lds_fence();
+        FFC_TICK(0)
         load_kf(a, h, un.wq * GEO::TPW, kf0);        // in flight across phase A and the barrier
         outer_stage<true, HALF>(a.L, un);
+        FFC_TICK(1)
       }
       const int pn = p + GEO::UPW;
       if (PREFETCH && pn < p1) rows_load<NC>(a, h, pn, un, X);   // lands while phases B/C run
       B::barrier();
+      FFC_TICK(2)
       if (act) {
         InnerRegs R;
         load_inner(R);
@@ -659,12 +667,23 @@ struct Body {
           kf0 = kfn;
         }
       }
+      FFC_TICK(3)
       B::barrier();
+      FFC_TICK(4)
       if (act) {
         outer_stage<false, HALF>(a.L, un);
         B::lds_fence();
+        FFC_TICK(5)
         rows_out<NC>(a, h, p, un);
+        FFC_TICK(6)
       }
+    }
+#undef FFC_TICK
+    if (PROF && a.prof) {
+      const i32 lane = B::lane();
+      unsigned long long* dst = a.prof + ((long long)wg_linear * GEO::WGW + B::wave()) * 8;
+#pragma unroll
+      for (int k = 0; k < 8; k++) B::g_w64(dst, lane * 0 + k, B::u2_from64(acc[k]), lane < 1);
     }
   }
 

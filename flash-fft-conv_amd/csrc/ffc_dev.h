@@ -65,6 +65,8 @@ struct DevB {
   static FFC_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
   static FFC_FN u32 uconst(uint32_t c) { return c; }
   static FFC_FN i32 mul24(i32 a, i32 b) { return __mul24(a, b); }
+  static FFC_FN unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }
+  static FFC_FN U2 u2_from64(unsigned long long v) { return U2{(u32)v, (u32)(v >> 32)}; }
   static FFC_FN f32 i2f(i32 a) { return (float)a; }
   static FFC_FN f32 cos_rev(f32 x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: argument in revolutions
   static FFC_FN f32 sin_rev(f32 x) { return __builtin_amdgcn_sinf(x); }
@@ -194,7 +196,7 @@ static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* n
   int upw = 8 / p->hp.NW;                       // units a workgroup processes per iteration
   int pairs_per_iter = outer ? upw : upw * p->hp.G;
   int wg_per_cu = outer ? 1 : 2;
-  int mult = 2;
+  int mult = 2;   // see profiles/: larger values did not help (k_f re-reads are not the limiter)
   if (const char* e = getenv("FFC_WG_MULT")) mult = atoi(e) > 0 ? atoi(e) : 2;   // tuning knob
   int target = p->num_cu * wg_per_cu * mult;
   int iters_total = (npair + pairs_per_iter - 1) / pairs_per_iter;

@@ -34,7 +34,50 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.conj_kf = conj_kf;
   a.s_inv = (float)p->hp.s_inv;
+  a.flags = 0;
+  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+}
+
+// ---- profiling build (N = 32768, bf16 only): same body with s_memtime phase counters
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_prof_kernel(ConvArgs a) {
+  int h, chunk;
+  if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
+  using BD = Body<DevB, GEO, DT>;
+  BD::setup_tables(a.tab, a.t);
+  const int wv = DevB::wave();
+  typename BD::Unit un;
+  un.wq = wv % GEO::NW;
+  const int u = wv / GEO::NW;
+  un.eb = u * GEO::EBYTES;
+  const int p0 = chunk * a.ppc;
+  int p1 = p0 + a.ppc;
+  if (p1 > a.npair) p1 = a.npair;
+  if (16 * GEO::Mi >= a.L) BD::template outer_jobs<true, true>(a, h, p0, p1, u, un, blockIdx.x);
+  else BD::template outer_jobs<false, true>(a, h, p0, p1, u, un, blockIdx.x);
+}
+
+// prof: device buffer of gridDim*8*8 uint64 (zero-initialised by the caller); returns grid size in *grid_out
+extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* kf, void* y, int64_t B, int64_t H, int64_t L,
+                                 unsigned long long* prof, int* grid_out, void* stream) {
+  if (!p || p->hp.N != 32768 || p->hp.dtype != DT_BF16) return ffc_fail("prof build: N=32768 bf16 only");
+  using GEO = Geo<32, 32, 32>;
+  ConvArgs a{};
+  a.u = u; a.y = y; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv;
+  a.fast = (L % 8 == 0);
+  a.flags = 0;
+  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
+  a.prof = prof;
+  ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  static int rc = ffc_set_lds(conv_prof_kernel<GEO, DT_BF16>, GEO::LDS_BYTES);
+  if (rc) return rc;
+  int hpad = (a.H + 7) & ~7;
+  if (grid_out) *grid_out = hpad * a.nchunk;
+  hipLaunchKernelGGL((conv_prof_kernel<GEO, DT_BF16>), dim3(hpad * a.nchunk), dim3(512), GEO::LDS_BYTES, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : ffc_fail(hipGetErrorString(e));
 }

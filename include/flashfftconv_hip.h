@@ -82,6 +82,11 @@ int ffc_conv1d_bwd(const void* dout, const void* u, const void* w, void* du, flo
                    int in_dtype, int w_dtype, int64_t B, int64_t D, int64_t L, int K, int P, int is_bhl,
                    void* stream);
 
+/* Profiling build of the N=32768 bf16 forward kernel: per-wave cycle sums of its phases
+ * (rows-in, phase A, barrier, phase B, barrier, phase C, rows-out) in prof[grid][8 waves][8].  Tuning support. */
+int ffc_conv_fwd_prof(const ffc_plan* plan, const void* u, const void* kf, void* y, int64_t B, int64_t H, int64_t L,
+                      unsigned long long* prof, int* grid_out, void* stream);
+
 /* Hardware-primitive self test (MFMA lane layouts, ds_read_b64_tr_b16, packing): fills `out_host`
  * (host memory, 64*40 uint32) for comparison against the CPU wave simulator.  Test support. */
 int ffc_selftest_primitives(const uint32_t* in_host, uint32_t* out_host);
