@@ -39,7 +39,7 @@ struct ConvArgs {
   int conj_kf;           // 1: multiply by conj(k_f)  (input-gradient pass)
   int fast;              // 1: L % 8 == 0 and 16-byte aligned tensors -> 16-byte global accesses
   float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
-  int flags;             // bit0: prefetch the next pair's rows (HALF job loop)
+  int flags;             // reserved tuning flags
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -404,24 +404,6 @@ struct Body {
 #pragma unroll
     for (int s = 0; s < GEO::S1; s++)
       colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
-    U2 rawr[2][8], rawi[2][8];
-#pragma unroll
-    for (int ms = 0; ms < 2; ms++) {
-      if (ms >= ms_lim) continue;
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
-        const int s1 = c / GEO::N1, rwc = c % GEO::N1;
-        i32 off = colb[s1] + rwc * (GEO::Mi * 2);
-        U2 vr = B::lds_r64(off), vi = B::lds_r64(off + GEO::PLANE);
-        if (FWD) {
-          pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
-          vr.x = B::sel(ok, vr.x, B::uconst(0)); vr.y = B::sel(ok, vr.y, B::uconst(0));
-          vi.x = B::sel(ok, vi.x, B::uconst(0)); vi.y = B::sel(ok, vi.y, B::uconst(0));
-        }
-        rawr[ms][e] = vr; rawi[ms][e] = vi;
-      }
-    }
     Mat F1;
     lds_mat(F1, GEO::L_F1);
     CT16 tw;
@@ -430,7 +412,26 @@ struct Body {
       cmul_small(tw, GEO::L_OMEGA + 256 * w);
     }
 #pragma unroll 1
-    for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): kept a runtime loop to bound live ranges
+    for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): a runtime loop bounds the live ranges
+      // raw rows of this tile pair: dword tp of each 8-byte chunk (elements 2tp, 2tp+1 = the two tiles)
+      u32 rawr[2][8], rawi[2][8];
+#pragma unroll
+      for (int ms = 0; ms < 2; ms++) {
+        if (ms >= ms_lim) continue;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
+          const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+          i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+          u32 vr = B::lds_r32(off), vi = B::lds_r32(off + GEO::PLANE);
+          if (FWD) {
+            pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
+            vr = B::sel(ok, vr, B::uconst(0));
+            vi = B::sel(ok, vi, B::uconst(0));
+          }
+          rawr[ms][e] = vr; rawi[ms][e] = vi;
+        }
+      }
       u32 sre[16], sim[16];
 #pragma unroll
       for (int th = 0; th < 2; th++) {
@@ -438,8 +439,12 @@ struct Body {
 #pragma unroll
         for (int ms = 0; ms < 2; ms++) {
           if (ms >= ms_lim) continue;
-          xpose2(rawr[ms], tp, th, op.r[ms]);
-          xpose2(rawi[ms], tp, th, op.i[ms]);
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            u32 ar = rawr[ms][2 * d], br = rawr[ms][2 * d + 1], ai = rawi[ms][2 * d], bi = rawi[ms][2 * d + 1];
+            op.r[ms][d] = th ? ((ar >> 16) | (br & 0xffff0000u)) : ((ar & 0xffffu) | (br << 16));
+            op.i[ms][d] = th ? ((ai >> 16) | (bi & 0xffff0000u)) : ((ai & 0xffffu) | (bi << 16));
+          }
         }
         A16 re, im;
         re = B::a16_zero(); im = B::a16_zero();
@@ -450,9 +455,9 @@ struct Body {
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
+          if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
           u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
           u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
-          if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
           if (th == 1) {
             const int c = (r & 3) + 8 * (r >> 2);
             const int s1 = c / GEO::N1, rwc = c % GEO::N1;
@@ -631,38 +636,38 @@ struct Body {
   template <bool HALF, bool PROF = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
-    const bool PREFETCH = HALF && (a.flags & 1);
     const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
-    RowRegsT<NC> X;
-    if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
       const int p = p0 + it * GEO::UPW + u;
       const bool act = p < p1;
-      KfRegs kf0;
       if (PROF) t0 = B::clock();
       if (act) {
-        if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
-        rows_store<NC>(a, h, p, un, X);
+        {
+          RowRegsT<NC> X;
+          rows_load<NC>(a, h, p, un, X);
+          rows_store<NC>(a, h, p, un, X);
+        }
         B::lds_fence();
         FFC_TICK(0)
-        load_kf(a, h, un.wq * GEO::TPW, kf0);        // in flight across phase A and the barrier
         outer_stage<true, HALF>(a.L, un);
         FFC_TICK(1)
       }
-      const int pn = p + GEO::UPW;
-      if (PREFETCH && pn < p1) rows_load<NC>(a, h, pn, un, X);   // lands while phases B/C run
       B::barrier();
       FFC_TICK(2)
       if (act) {
+        // no long-latency global load may be outstanding while a phase runs: vmcnt retires in order, so
+        // anything the compiler spills would wait behind it.  k_f is prefetched one tile ahead only here.
+        KfRegs kf0;
+        load_kf(a, h, un.wq * GEO::TPW, kf0);
         InnerRegs R;
         load_inner(R);
 #pragma unroll 1
         for (int tt = 0; tt < GEO::TPW; tt++) {
           KfRegs kfn;
-          if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);   // next tile's k_f in flight
+          if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);
           inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
           kf0 = kfn;
         }
@@ -689,6 +694,8 @@ struct Body {
 
   // ------------------------------------------------------------------ workgroup entry: conv
   // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
+  // HALF is chosen by the launcher: 32-point outer digit and L <= N/2
+  template <bool HALF = false>
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
     setup_tables(a.tab, a.t);
     const int wv = B::wave();
@@ -700,8 +707,7 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) outer_jobs<true>(a, h, p0, p1, u, un);
-      else outer_jobs<false>(a, h, p0, p1, u, un);
+      outer_jobs<HALF && GEO::S1 == 1>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -56,6 +56,7 @@ struct DevB {
     if (p) *(uint4*)(ffc_smem + off) = make_uint4(v.x, v.y, v.z, v.w);
   }
   static FFC_FN U4 lds_r128(i32 off) { uint4 v = *(const uint4*)(ffc_smem + off); return U4{v.x, v.y, v.z, v.w}; }
+  static FFC_FN u32 lds_r32(i32 off) { return *(const uint32_t*)(ffc_smem + off); }
   static FFC_FN u32 lds_r16(i32 off) { return *(const uint16_t*)(ffc_smem + off); }
   static FFC_FN U2 lds_r64_tr(i32 off) {
     s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ffc_smem + off));

@@ -2,20 +2,27 @@
 #include "ffc_dev.h"
 using namespace ffc;
 
-template <class GEO, int DT>
+template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
   int h, chunk;
   if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
-  Body<DevB, GEO, DT>::conv(a, h, chunk);
+  Body<DevB, GEO, DT>::template conv<HALF>(a, h, chunk);
 }
 
 template <class GEO, int DT>
 struct ConvLaunch {
   static int run(const ConvArgs& a, hipStream_t st) {
-    static int rc = ffc_set_lds(conv_kernel<GEO, DT>, GEO::LDS_BYTES);
-    if (rc) return rc;
     int hpad = (a.H + 7) & ~7;
-    hipLaunchKernelGGL((conv_kernel<GEO, DT>), dim3(hpad * a.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
+    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= a.L) {
+      static int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((conv_kernel<GEO, DT, true>), dim3(hpad * a.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    } else {
+      static int rc = ffc_set_lds(conv_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((conv_kernel<GEO, DT, false>), dim3(hpad * a.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel launch: ") + hipGetErrorString(e));
   }

@@ -109,6 +109,11 @@ struct SimB {
     }
     return r;
   }
+  static u32 lds_r32(const i32& off) {
+    u32 r;
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 4); memcpy(&r.v[i], L() + off.v[i], 4); }
+    return r;
+  }
   static u32 lds_r16(const i32& off) {
     u32 r;
     for (int i = 0; i < 64; i++) { chk(off.v[i], 2); uint16_t h; memcpy(&h, L() + off.v[i], 2); r.v[i] = h; }
