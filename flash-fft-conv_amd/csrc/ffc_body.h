@@ -39,6 +39,7 @@ struct ConvArgs {
   int conj_kf;           // 1: multiply by conj(k_f)  (input-gradient pass)
   int fast;              // 1: L % 8 == 0 and 16-byte aligned tensors -> 16-byte global accesses
   float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
+  float s_fwd;           // forward scale, applied with the outer forward twiddle (fused sizes >= 4096)
   int flags;             // reserved tuning flags
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
@@ -122,6 +123,27 @@ struct Body {
       im[r] = b * t.re[r] - a * t.im[r];
     }
   }
+  // Twiddle chain: t[i] = scale * cis(sign * 2*pi * ((base + off_i*step) mod N) / N) for the 8 row offsets
+  // off = {0,1,2,3,8,9,10,11} an accumulator half holds: three v_sin/v_cos pairs (exact integer phases,
+  // argument in revolutions) and seven complex multiplies instead of 8 sincos + per-element phase math.
+  static FFC_FN void cis_rev(i32 phase, float sign, f32* c, f32* s) {
+    f32 x = B::i2f(phase & (GEO::N - 1)) * (1.0f / (float)GEO::N);
+    *c = B::cos_rev(x);
+    *s = B::sin_rev(x) * sign;
+  }
+  static FFC_FN void chain8(i32 base, i32 step, float sign, float scale, f32 (&tr)[8], f32 (&ti)[8]) {
+    f32 c0, s0, c1, s1, c8, s8;
+    cis_rev(base, sign, &c0, &s0);
+    cis_rev(step, sign, &c1, &s1);
+    cis_rev(step * 8, sign, &c8, &s8);
+    tr[0] = c0 * scale; ti[0] = s0 * scale;
+    tr[4] = tr[0] * c8 - ti[0] * s8; ti[4] = tr[0] * s8 + ti[0] * c8;
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+      tr[i] = tr[i - 1] * c1 - ti[i - 1] * s1; ti[i] = tr[i - 1] * s1 + ti[i - 1] * c1;
+      tr[4 + i] = tr[3 + i] * c1 - ti[3 + i] * s1; ti[4 + i] = tr[3 + i] * s1 + ti[3 + i] * c1;
+    }
+  }
   // dtype pair (x) dtype pair, rounded back to dtype (the reference multiplies gates in the
   // activation dtype: kernels_bf16/monarch_cuda_32_32_32_kernel_bf16.h:409-429, 613-634).
   static FFC_FN u32 mul2(u32 a, u32 g) {
@@ -162,9 +184,6 @@ struct Body {
   static FFC_FN void setup_tables(const uint8_t* tab, const PlanTabs& t) {
     if constexpr (GEO::OUTER) {
       copy_tab(tab + t.mat[0], GEO::L_F1, 6144);
-      copy_tab(tab + t.base, GEO::L_BASE, 8192);
-      copy_tab(tab + t.delta, GEO::L_DELTA, 256);
-      copy_tab(tab + t.omega, GEO::L_OMEGA, 256 * GEO::NW);
     }
     copy_tab(tab + t.mat[1], GEO::L_F2, 6144);
     copy_tab(tab + t.twin, GEO::L_TW, 8192);
@@ -392,7 +411,7 @@ struct Body {
   // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
   // HALF: input rows n1 >= 16 are all zero (L <= 16*Mi, 32-point outer digit) -> one K-step.
   template <bool FWD, bool HALF>
-  static FFC_FN void outer_stage(int L, Unit un) {
+  static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
@@ -406,11 +425,6 @@ struct Body {
       colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
     Mat F1;
     lds_mat(F1, GEO::L_F1);
-    CT16 tw;
-    if (FWD) {
-      lds_ct16(tw, GEO::L_BASE);
-      cmul_small(tw, GEO::L_OMEGA + 256 * w);
-    }
 #pragma unroll 1
     for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): a runtime loop bounds the live ranges
       // raw rows of this tile pair: dword tp of each 8-byte chunk (elements 2tp, 2tp+1 = the two tiles)
@@ -450,8 +464,22 @@ struct Body {
         re = B::a16_zero(); im = B::a16_zero();
         cmm<!FWD, false>(re, im, op, F1, ms_lim);
         if (FWD) {
-          if (tp + th > 0) cmul_small(tw, GEO::L_DELTA);
-          cmul(re, im, tw);
+          // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
+#pragma unroll
+          for (int half = 0; half < 2; half++) {     // accumulator registers 0-7 / 8-15 (rows +16)
+            const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
+            i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + 2 * tp + th);
+            i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
+            f32 tr[8], ti[8];
+            chain8(m * k0, m, -1.0f, s_fwd, tr, ti);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              const int r = 8 * half + i;
+              f32 x = re[r], y = im[r];
+              re[r] = x * tr[i] - y * ti[i];
+              im[r] = x * ti[i] + y * tr[i];
+            }
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -474,28 +502,48 @@ struct Body {
   }
 
   // ------------------------------------------------------------------ phase B (inner tile)
-  static FFC_FN void load_tile_op(int tau, Op& op, Unit un) {
-    const i32 lane = B::opaque(B::lane());
+  // per-lane LDS offsets of tile 0 (tile tau adds tau*G rows): operand reads [K-step][rho] and write-back [rq]
+  struct InnerRegs { Mat F2; CT16 tw; i32 roff[2][2]; i32 woff[4]; };
+  static FFC_FN void load_inner(InnerRegs& R, Unit un) {
+    lds_mat(R.F2, GEO::L_F2);
+    lds_ct16(R.tw, GEO::L_TW);
+    const i32 lane = B::lane();
     const i32 c = lane & 31, hi = lane >> 5;
-    const i32 sV = c / GEO::N3;
+    const i32 i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const i32 n3b = (g16 * 16) % GEO::N3;
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+      for (int rho = 0; rho < 2; rho++) {
+        i32 U = hi * 4 + (16 * ms + 8 * rho) + (i16 >> 2);
+        i32 sU = U / GEO::N2, n2 = U % GEO::N2;
+        i32 row = sU * GEO::SV + ((g16 * 16) / GEO::N3);
+        R.roff[ms][rho] = e_off<GEO, i32>(row, n2 * GEO::N3 + n3b + (i16 & 3) * 4) + un.eb;
+      }
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 V = hi * 4 + 8 * rq;
+      i32 row = (c / GEO::N2) * GEO::SV + V / GEO::N3;
+      R.woff[rq] = e_off<GEO, i32>(row, (c % GEO::N2) * GEO::N3 + V % GEO::N3) + un.eb;
+    }
+  }
+
+  static FFC_FN void load_tile_op(int tau, Op& op, Unit un, const InnerRegs& R) {
+    const int trow = tau * (GEO::G * GEO::Mi * 2);
     if (B::HAS_TR) {
-      const i32 i16 = lane & 15, g16 = (lane >> 4) & 1;
-      const i32 n3b = (g16 * 16) % GEO::N3;
 #pragma unroll
       for (int ms = 0; ms < 2; ms++)
 #pragma unroll
         for (int rho = 0; rho < 2; rho++) {
-          i32 U = hi * 4 + (16 * ms + 8 * rho) + (i16 >> 2);   // this lane supplies row U
-          i32 sU = U / GEO::N2, n2 = U % GEO::N2;
-          i32 row = sU * GEO::SV + ((g16 * 16) / GEO::N3) + tau * GEO::G;
-          i32 m = n2 * GEO::N3 + n3b + (i16 & 3) * 4;
-          i32 off = e_off<GEO, i32>(row, m) + un.eb;
+          i32 off = R.roff[ms][rho] + trow;
           U2 vr = B::lds_r64_tr(off), vi = B::lds_r64_tr(off + GEO::PLANE);
           op.r[ms][2 * rho] = vr.x; op.r[ms][2 * rho + 1] = vr.y;
           op.i[ms][2 * rho] = vi.x; op.i[ms][2 * rho + 1] = vi.y;
         }
     } else {
-      const i32 n3 = c % GEO::N3;
+      const i32 lane = B::opaque(B::lane());
+      const i32 c = lane & 31, hi = lane >> 5;
+      const i32 sV = c / GEO::N3, n3 = c % GEO::N3;
 #pragma unroll
       for (int ms = 0; ms < 2; ms++)
 #pragma unroll
@@ -517,16 +565,10 @@ struct Body {
     }
   }
 
-  struct InnerRegs { Mat F2; CT16 tw; };
-  static FFC_FN void load_inner(InnerRegs& R) {
-    lds_mat(R.F2, GEO::L_F2);
-    lds_ct16(R.tw, GEO::L_TW);
-  }
-
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
   static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
     Op op;
-    load_tile_op(tau, op, un);
+    load_tile_op(tau, op, un, R);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
     cmm<false, true>(re, im, op, R.F2);
@@ -571,27 +613,28 @@ struct Body {
     // outer inverse twiddle s_inv * W_N^{-(n2*N3+n3)*k1}, generated on the fly (v_sin/v_cos take
     // revolutions; the integer phase m*k1 mod N is exact), so no table traffic in the tile loop
     if constexpr (GEO::OUTER) {
+      // registers <-> V = (sV, n3) = 4*hi + {0..3} + 8*{0..3}; lane <-> (sU, n2); E row k1 = tau*G + sU*SV + sV
       const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        i32 V = hi * 4 + ((r & 3) + 8 * (r >> 2));
-        i32 k1 = sUl * GEO::SV + V / GEO::N3 + tau * GEO::G;
-        i32 ph = B::mul24(mlane + V % GEO::N3, k1) & (GEO::N - 1);
-        f32 x = B::i2f(ph) * (1.0f / (float)GEO::N);
-        f32 tr = B::cos_rev(x) * s_inv, ti = B::sin_rev(x) * s_inv;   // conj(W^{m k1}) = cos + i sin
-        f32 xr = re[r], xi = im[r];
-        re[r] = xr * tr - xi * ti;
-        im[r] = xr * ti + xi * tr;
+      for (int half = 0; half < 2; half++) {
+        const int sV = (16 * half) / GEO::N3;
+        i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
+        i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
+        f32 tr[8], ti[8];
+        chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);     // conj(W^{m k1}) = cos + i sin
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int r = 8 * half + i;
+          f32 x = re[r], y = im[r];
+          re[r] = x * tr[i] - y * ti[i];
+          im[r] = x * ti[i] + y * tr[i];
+        }
       }
     }
     // write back in place: lane <-> (sU,n2), regs <-> (sV,n3); r&3 = 4 consecutive n3
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
-      i32 V = hi * 4 + 8 * rq;
-      i32 sV = V / GEO::N3, n3 = V % GEO::N3;
-      i32 sU = c / GEO::N2, n2 = c % GEO::N2;
-      i32 row = sU * GEO::SV + sV + tau * GEO::G;
-      i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3) + un.eb;
+      i32 off = R.woff[rq] + tau * (GEO::G * GEO::Mi * 2);
       U2 vr, vi;
       vr.x = B::template pack<DT>(re[4 * rq], re[4 * rq + 1]);
       vr.y = B::template pack<DT>(re[4 * rq + 2], re[4 * rq + 3]);
@@ -652,7 +695,7 @@ struct Body {
         }
         B::lds_fence();
         FFC_TICK(0)
-        outer_stage<true, HALF>(a.L, un);
+        outer_stage<true, HALF>(a.L, un, a.s_fwd);
         FFC_TICK(1)
       }
       B::barrier();
@@ -663,7 +706,7 @@ struct Body {
         KfRegs kf0;
         load_kf(a, h, un.wq * GEO::TPW, kf0);
         InnerRegs R;
-        load_inner(R);
+        load_inner(R, un);
 #pragma unroll 1
         for (int tt = 0; tt < GEO::TPW; tt++) {
           KfRegs kfn;
@@ -713,7 +756,7 @@ struct Body {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
       InnerRegs R;
-      load_inner(R);
+      load_inner(R, un);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int q = q0 + it * GEO::UPW + u;

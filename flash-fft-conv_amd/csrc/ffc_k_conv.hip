@@ -40,7 +40,7 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.conj_kf = conj_kf;
-  a.s_inv = (float)p->hp.s_inv;
+  a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.flags = 0;
   if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
@@ -74,7 +74,7 @@ extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* k
   using GEO = Geo<32, 32, 32>;
   ConvArgs a{};
   a.u = u; a.y = y; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs;
-  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0);
   a.flags = 0;
   if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);

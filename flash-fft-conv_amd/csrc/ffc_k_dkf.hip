@@ -63,7 +63,7 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   DkfArgs d{};
   ConvArgs& a = d.c;
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
-  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
@@ -82,7 +82,7 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
   DkfArgs d{};
   ConvArgs& a = d.c;
   a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
-  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv;
+  a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);

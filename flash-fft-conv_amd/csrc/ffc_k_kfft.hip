@@ -24,6 +24,7 @@ extern "C" int ffc_kernel_fft(const ffc_plan* p, const float* k, int64_t H, int6
   if (H * Lk >= ((int64_t)1 << 31)) return ffc_fail("k too large");
   KfArgs a{};
   a.k = k; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = (int)Lk;
+  a.s_fwd = (float)p->hp.s_fwd;
   a.prescale = p->hp.dtype == DT_F16 ? 256.f : 1.f;
   a.scale = (float)(p->hp.s_k / p->hp.s_fwd) / a.prescale;
   a.fast = (Lk % 4 == 0) && !((uintptr_t)k & 15);
@@ -35,6 +36,6 @@ extern "C" int ffc_kernel_fft_c(const ffc_plan* p, const void* xpair, int64_t H,
   if (!p || !xpair || !kf) return ffc_fail("null arg");
   if (p->hp.N1 <= 1) return ffc_fail("ffc_kernel_fft_c: inner size must be >= 4096");
   KfArgs a{};
-  a.xpair = xpair; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = p->hp.N; a.scale = scale; a.prescale = 1.f; a.fast = 1;
+  a.xpair = xpair; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = p->hp.N; a.scale = scale; a.prescale = 1.f; a.s_fwd = (float)p->hp.s_fwd; a.fast = 1;
   return ffc_dispatch<KfLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }

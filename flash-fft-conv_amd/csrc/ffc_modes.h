@@ -19,6 +19,7 @@ struct KfArgs {
   PlanTabs t;
   int H, Lk;
   float scale;         // s_k / (s_fwd * prescale)
+  float s_fwd;         // plan forward scale (outer forward twiddle)
   float prescale;      // applied to k before rounding to dtype (2^8 in fp16 mode: k's energy sits in a few taps,
                        // its scaled spectrum would otherwise fall into the fp16 subnormal range)
   const void* xpair;   // optional complex input instead of k: pair-plane tensor (2, H, M) dtype (big FFT sizes)
@@ -146,7 +147,7 @@ struct Modes : Body<B, GEO, DT> {
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
     const bool act = unit_id < nunits;
     InnerRegs R;
-    BD::load_inner(R);
+    BD::load_inner(R, un);
     if constexpr (GEO::OUTER) {
       if (act) {
         if (a.xpair) {
@@ -157,8 +158,8 @@ struct Modes : Body<B, GEO, DT> {
           k_rows_in(a, unit_id, un);
         }
         B::lds_fence();
-        if (GEO::S1 == 1 && 16 * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un);
-        else BD::template outer_stage<true, false>(a.Lk, un);
+        if (GEO::S1 == 1 && 16 * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
+        else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
       }
       B::barrier();
       if (act) {
@@ -304,12 +305,12 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(av, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
-          else BD::template outer_stage<true, false>(a.L, un);
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
+          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R);
+          BD::load_inner(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
@@ -321,12 +322,12 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(ad, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
-          else BD::template outer_stage<true, false>(a.L, un);
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
+          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R);
+          BD::load_inner(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             const int tau = un.wq * GEO::TPW + tt;
@@ -345,7 +346,7 @@ struct Modes : Body<B, GEO, DT> {
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
-      BD::load_inner(R);
+      BD::load_inner(R, un);
       A16 wre, wim;
       wre = B::a16_zero(); wim = B::a16_zero();
 #pragma unroll 1
@@ -424,12 +425,12 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(av, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
-          else BD::template outer_stage<true, false>(a.L, un);
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
+          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R);
+          BD::load_inner(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
@@ -441,12 +442,12 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(ad, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un);
-          else BD::template outer_stage<true, false>(a.L, un);
+          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
+          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R);
+          BD::load_inner(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             const int tau = un.wq * GEO::TPW + tt;
@@ -475,7 +476,7 @@ struct Modes : Body<B, GEO, DT> {
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
-      BD::load_inner(R);
+      BD::load_inner(R, un);
       A16 wre = B::a16_zero(), wim = B::a16_zero();
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
@@ -611,7 +612,7 @@ struct Modes : Body<B, GEO, DT> {
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
     const bool act = unit_id < nunits;
     InnerRegs R;
-    BD::load_inner(R);
+    BD::load_inner(R, un);
     if constexpr (GEO::OUTER) {
       if (act) {
 #pragma unroll 1

@@ -355,7 +355,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
   a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
-  a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv;
+  a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
   a.fast = (L % 8 == 0) && !g_force_slow;
   return dispatch<ConvRun>(N, dtype, a);
 }
@@ -390,7 +390,7 @@ int ffcsim_kernel_fft_c(int N, int dtype, const void* xpair, int H, void* kf, fl
   HostPlan p;
   if (!build_plan(N, dtype, &p)) return -1;
   KfArgs a{};
-  a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.prescale = 1.f; a.fast = 1;
+  a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.prescale = 1.f; a.s_fwd = (float)p.s_fwd; a.fast = 1;
   return dispatch<KfRun>(N, dtype, a);
 }
 
@@ -399,6 +399,7 @@ int ffcsim_kernel_fft(int N, int dtype, const float* k, int H, int Lk, void* kf)
   if (!build_plan(N, dtype, &p)) return -1;
   KfArgs a{};
   a.k = k; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk;
+  a.s_fwd = (float)p.s_fwd;
   a.prescale = dtype == DT_F16 ? 256.f : 1.f;
   a.scale = (float)(p.s_k / p.s_fwd) / a.prescale; a.fast = (Lk % 4 == 0) && !g_force_slow;
   return dispatch<KfRun>(N, dtype, a);
@@ -412,7 +413,7 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   DkfArgs d{};
   ConvArgs& a = d.c;
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
-  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
+  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_fwd = (float)p.s_fwd;
   int upw = ffcsim_upw(N);
   int per_iter = p.N1 > 1 ? upw : upw * p.G;
   int iters_total = (a.npair + per_iter - 1) / per_iter;
@@ -435,7 +436,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   DkfArgs d{};
   ConvArgs& a = d.c;
   a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
-  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_inv = (float)p.s_inv;
+  a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
   int upw = ffcsim_upw(N);
   int per_iter = p.N1 > 1 ? upw : upw * p.G;
   int iters_total = (a.npair + per_iter - 1) / per_iter;
