@@ -28,3 +28,19 @@ for N, B, H in ((4096, 2, 8), (4096, 16, 8), (8192, 2, 3)):
     print(N, B, H, "dk(dkf) %.2e dk(fused) %.2e  slabs equal: %s  maxdiff %.3e" % (rel(d1, ref), rel(d2, ref), torch.equal(w1[:H*N*2], w2[:H*N*2]), (w1[:H*N*2*8]-w2[:H*N*2*8]).abs().max().item()))
     print("   per-head dkf:", ["%.1e" % rel(d1[h], ref[h]) for h in range(H)])
     e = (d1 - ref).abs(); print("   worst positions head0:", e[0].topk(5).indices.tolist(), " ref scale %.2f" % ref.abs().mean().item())
+print("--- determinism of the dk inverse (same workspace, repeated)")
+for N, B, H in ((4096, 2, 8), (8192, 2, 3), (16384, 2, 3)):
+    torch.manual_seed(0)
+    L = N // 2
+    u = torch.randn(B, H, L, device="cuda").to(dtype); dout = torch.randn(B, H, L, device="cuda").to(dtype)
+    mod = FlashFFTConv(N, dtype=dtype).to("cuda"); plan = mod._get_plan(u.device); lib = _lib.lib()
+    nb = lib.ffc_dkf_workspace_bytes(plan.handle, B, H)
+    ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(u), None, None, _lib.ptr(ws), B, H, L, None), "dkf")
+    ref = torch.fft.ifft((torch.fft.fft(dout.float(), n=N) * torch.fft.fft(u.float(), n=N).conj()).sum(0)).real[:, :L]
+    outs = []
+    for i in range(4):
+        dk = torch.full((H, L), float("nan"), dtype=torch.float32, device="cuda")
+        _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, L, _lib.ptr(dk), None), "ifft")
+        torch.cuda.synchronize(); outs.append(dk)
+    print(N, [("%.2e" % rel(o, ref)) for o in outs], "identical:", [torch.equal(outs[0], o) for o in outs[1:]], "nan:", [int(torch.isnan(o).sum()) for o in outs])
