@@ -128,8 +128,10 @@ struct Body {
   // argument in revolutions) and seven complex multiplies instead of 8 sincos + per-element phase math.
   static FFC_FN void cis_rev(i32 phase, float sign, f32* c, f32* s) {
     f32 x = B::i2f(phase & (GEO::N - 1)) * (1.0f / (float)GEO::N);
-    *c = B::cos_rev(x);
-    *s = B::sin_rev(x) * sign;
+    f32 cc = B::cos_rev(x), ss = B::sin_rev(x);
+    B::settle(cc, ss);     // see DevB::settle: transcendental results are fenced before packed-math consumers
+    *c = cc;
+    *s = ss * sign;
   }
   static FFC_FN void chain8(i32 base, i32 step, float sign, float scale, f32 (&tr)[8], f32 (&ti)[8]) {
     f32 c0, s0, c1, s1, c8, s8;

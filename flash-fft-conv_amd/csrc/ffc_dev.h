@@ -68,6 +68,10 @@ struct DevB {
   static FFC_FN i32 mul24(i32 a, i32 b) { return __mul24(a, b); }
   static FFC_FN unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }
   static FFC_FN U2 u2_from64(unsigned long long v) { return U2{(u32)v, (u32)(v >> 32)}; }
+  // v_sin/v_cos run on the transcendental unit; consumers scheduled right behind them (packed f32 math in
+  // particular) were observed to read stale operands on gfx950 (timing-dependent 1-3% errors, caught by a
+  // run-to-run determinism check).  An opaque asm with wait states orders them conservatively.
+  static FFC_FN void settle(f32& a, f32& b) { asm volatile("s_nop 4" : "+v"(a), "+v"(b)); }
   static FFC_FN f32 i2f(i32 a) { return (float)a; }
   static FFC_FN f32 cos_rev(f32 x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: argument in revolutions
   static FFC_FN f32 sin_rev(f32 x) { return __builtin_amdgcn_sinf(x); }
