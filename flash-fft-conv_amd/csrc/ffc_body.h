@@ -587,7 +587,7 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
+  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     Op op;
@@ -617,6 +617,19 @@ struct Body {
     if constexpr (GEO::OUTER) {
       // registers <-> V = (sV, n3) = 4*hi + {0..3} + 8*{0..3}; lane <-> (sU, n2); E row k1 = tau*G + sU*SV + sV
       const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
+      if (dbg & 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          i32 V = hi * 4 + ((r & 3) + 8 * (r >> 2));
+          i32 k1 = sUl * GEO::SV + V / GEO::N3 + tau * GEO::G;
+          f32 tr, ti;
+          cis_rev(B::mul24(mlane + V % GEO::N3, k1), 1.0f, &tr, &ti);
+          tr = tr * s_inv; ti = ti * s_inv;
+          f32 xr = re[r], xi = im[r];
+          re[r] = xr * tr - xi * ti;
+          im[r] = xr * ti + xi * tr;
+        }
+      } else
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         const int sV = (16 * half) / GEO::N3;

@@ -29,6 +29,7 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   a.nslab = nchunk * (8 / p->hp.NW);
   a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }
 

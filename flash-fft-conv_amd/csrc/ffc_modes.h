@@ -47,6 +47,7 @@ struct DkArgs {
   int H, Lk, nslab;
   float scale;         // 1 / s_fwd  (W carries s_fwd^2, the inverse applies 1/(N s_fwd))
   float s_inv;         // plan's 1/(N*s_fwd) (applied inside tile_inv for fused sizes >= 4096)
+  int flags;           // debugging switches
   void* outpair;       // optional complex output instead of dk: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;
 };
@@ -619,7 +620,7 @@ struct Modes : Body<B, GEO, DT> {
         for (int tt = 0; tt < GEO::TPW; tt++) {
           A16 re, im;
           w_load(a, unit_id, un.wq * GEO::TPW + tt, re, im);
-          BD::tile_inv(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im);
+          BD::tile_inv(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im, a.flags);
         }
       }
       B::barrier();
