@@ -694,7 +694,12 @@ struct Body {
   template <bool HALF, bool PROF = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
+    // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
+    // arrive during the last tile / phase C / the stores and no earlier in-order vmcnt wait is delayed.
+    constexpr bool PREFETCH = HALF;
     const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+    RowRegsT<NC> X;
+    if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
@@ -703,11 +708,8 @@ struct Body {
       const bool act = p < p1;
       if (PROF) t0 = B::clock();
       if (act) {
-        {
-          RowRegsT<NC> X;
-          rows_load<NC>(a, h, p, un, X);
-          rows_store<NC>(a, h, p, un, X);
-        }
+        if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
+        rows_store<NC>(a, h, p, un, X);
         B::lds_fence();
         FFC_TICK(0)
         outer_stage<true, HALF>(a.L, un, a.s_fwd);
@@ -726,6 +728,7 @@ struct Body {
         for (int tt = 0; tt < GEO::TPW; tt++) {
           KfRegs kfn;
           if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);
+          else if (PREFETCH && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
           inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
           kf0 = kfn;
         }
