@@ -696,7 +696,7 @@ struct Body {
     constexpr int NC = HALF ? NCH / 2 : NCH;
     // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
     // arrive during the last tile / phase C / the stores and no earlier in-order vmcnt wait is delayed.
-    constexpr bool PREFETCH = HALF;
+    constexpr bool PREFETCH = false;   // measured: +5K cycles in phase B for -2.7K in rows_in (profiles/r01_phase_cycles.txt)
     const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
     RowRegsT<NC> X;
     if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
