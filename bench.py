@@ -2,7 +2,7 @@
 
 Step = one forward + backward of FlashFFTConv(32768) on BASELINE.json configs[1]
 (B=16, H=768, L=16384, bf16 activations, fp32 k), synthetic randn inputs resident in HBM:
-   k -> k_f (kfft kernel), conv forward, dk_f accumulation + dk inverse, input-gradient conv.
+   k -> k_f (kfft kernel), conv forward, fused backward (du + fp32 dk_f partial sums), dk inverse.
 Nothing is cached between steps (the reference recomputes k_f every forward, conv.py:572-575).
 N > 1 GPUs: one process per GPU, heads sharded (weak scaling: every rank runs the full per-GPU shape
 on its own heads, no data-path collective); barrier + max-over-ranks timing.
@@ -158,7 +158,10 @@ def main():
     alg_bytes = B * H * L * 2 * 2 + H * N * 4          # read u, write y, read k_f once
     roof = {"kernel": "conv_kernel<Geo<32,32,32>,bf16> (forward)", "bound": "mfma",
             "achieved": alg_flops / t_conv / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": alg_flops / t_conv / 1e12 / MFMA_PEAK_TFLOPS, "traffic": None,
+            "frac": alg_flops / t_conv / 1e12 / MFMA_PEAK_TFLOPS,
+            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
+            # profiles/r01_final_pmc_conv_kernel.txt; not re-measured inside bench.py
+            "traffic": 1611.6e6, "traffic_source": "profiles/r01_final_pmc_conv_kernel.txt",
             "launch_ms": t_conv * 1e3,
             "hbm_GBs": alg_bytes / t_conv / 1e9, "hbm_frac": alg_bytes / t_conv / 1e9 / HBM_PEAK_GBS,
             "basis": "SURVEY 8(d): dense Monarch 42.9 MFLOP/row (reference 32x32x32 factorisation) x rows; our pair-packed kernel executes ~half of these"}
