@@ -506,9 +506,10 @@ struct Body {
   // ------------------------------------------------------------------ phase B (inner tile)
   // per-lane LDS offsets of tile 0 (tile tau adds tau*G rows): operand reads [K-step][rho] and write-back [rq]
   struct InnerRegs { Mat F2; CT16 tw; i32 roff[2][2]; i32 woff[4]; };
+  template <bool TWR = true>
   static FFC_FN void load_inner(InnerRegs& R, Unit un) {
     lds_mat(R.F2, GEO::L_F2);
-    lds_ct16(R.tw, GEO::L_TW);
+    if constexpr (TWR) lds_ct16(R.tw, GEO::L_TW);
     const i32 lane = B::lane();
     const i32 c = lane & 31, hi = lane >> 5;
     const i32 i16 = lane & 15, g16 = (lane >> 4) & 1;
@@ -568,13 +569,22 @@ struct Body {
   }
 
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
+  // TWR: inner twiddle table resident in registers (R.tw); false -> re-read from LDS at each use (saves 32
+  // VGPRs in the register-heavy backward kernels)
+  template <bool TWR = true>
   static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
     Op op;
     load_tile_op(tau, op, un, R);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
     cmm<false, true>(re, im, op, R.F2);
-    cmul(re, im, R.tw);
+    if constexpr (TWR) {
+      cmul(re, im, R.tw);
+    } else {
+      CT16 tw;
+      lds_ct16(tw, GEO::L_TW);
+      cmul(re, im, tw);
+    }
     to_op(re, im, op);
     // stage b: contract n3 (B-form) -> [V'=(sV,k3) regs][U' lanes]
     re = B::a16_zero(); im = B::a16_zero();
@@ -587,6 +597,7 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
+  template <bool TWR = true>
   static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
@@ -605,8 +616,12 @@ struct Body {
       CT16 tw2;
       lds_ct16(tw2, GEO::L_TW2);
       cmul(re, im, tw2);
-    } else {
+    } else if constexpr (TWR) {
       cmul_conj(re, im, R.tw);
+    } else {
+      CT16 tw;
+      lds_ct16(tw, GEO::L_TW);
+      cmul_conj(re, im, tw);
     }
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]

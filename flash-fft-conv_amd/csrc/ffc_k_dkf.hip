@@ -2,37 +2,49 @@
 #include "ffc_dev.h"
 using namespace ffc;
 
-template <class GEO, int DT>
+template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::dkf(d, h, chunk, blockIdx.x);
+  Modes<DevB, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct DkfLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
-    static int rc = ffc_set_lds(dkf_kernel<GEO, DT>, GEO::LDS_BYTES);
-    if (rc) return rc;
     int hpad = (d.c.H + 7) & ~7;
-    hipLaunchKernelGGL((dkf_kernel<GEO, DT>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= d.c.L) {
+      static int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((dkf_kernel<GEO, DT, true>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    } else {
+      static int rc = ffc_set_lds(dkf_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((dkf_kernel<GEO, DT, false>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("dkf_kernel launch: ") + hipGetErrorString(e));
   }
 };
 
-template <class GEO, int DT>
+template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::bwd(d, h, chunk, blockIdx.x);
+  Modes<DevB, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct BwdLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
-    static int rc = ffc_set_lds(bwd_kernel<GEO, DT>, GEO::LDS_BYTES);
-    if (rc) return rc;
     int hpad = (d.c.H + 7) & ~7;
-    hipLaunchKernelGGL((bwd_kernel<GEO, DT>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= d.c.L) {
+      static int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    } else {
+      static int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+      if (rc) return rc;
+      hipLaunchKernelGGL((bwd_kernel<GEO, DT, false>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_kernel launch: ") + hipGetErrorString(e));
   }

@@ -208,6 +208,45 @@ struct Modes : Body<B, GEO, DT> {
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
   }
+  // previous partial sums of a tile, issued at the start of the tile so the latency overlaps tile_fwd
+  struct WOld { U4 v[4][2]; };
+  static FFC_FN void w_load_old(const float* slab, int tau, bool first, WOld& o) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2;
+      o.v[rq][0] = B::g_r128p(slab, idx, !first ? B::ptrue() : B::pfalse());
+      o.v[rq][1] = B::g_r128p(slab, idx + 1, !first ? B::ptrue() : B::pfalse());
+    }
+  }
+  static FFC_FN void w_update(float* slab, int tau, const WOld& o, const typename BD::KfRegs& zv, const A16& re, const A16& im) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) * 2;
+      u32 wv[4] = {zv.v[rq].x, zv.v[rq].y, zv.v[rq].z, zv.v[rq].w};
+      f32 wr[4], wi[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * rq + q;
+        f32 ur = B::template unpack_lo<DT>(wv[q]), ui = B::template unpack_hi<DT>(wv[q]);
+        wr[q] = re[r] * ur + im[r] * ui;
+        wi[q] = im[r] * ur - re[r] * ui;
+      }
+      const U4& o0 = o.v[rq][0]; const U4& o1 = o.v[rq][1];       // zeros on the first pair
+      wr[0] = wr[0] + B::as_f32(o0.x); wi[0] = wi[0] + B::as_f32(o0.y);
+      wr[1] = wr[1] + B::as_f32(o0.z); wi[1] = wi[1] + B::as_f32(o0.w);
+      wr[2] = wr[2] + B::as_f32(o1.x); wi[2] = wi[2] + B::as_f32(o1.y);
+      wr[3] = wr[3] + B::as_f32(o1.z); wi[3] = wi[3] + B::as_f32(o1.w);
+      U4 n0, n1;
+      n0.x = B::as_u32(wr[0]); n0.y = B::as_u32(wi[0]); n0.z = B::as_u32(wr[1]); n0.w = B::as_u32(wi[1]);
+      n1.x = B::as_u32(wr[2]); n1.y = B::as_u32(wi[2]); n1.z = B::as_u32(wr[3]); n1.w = B::as_u32(wi[3]);
+      B::g_w128(slab, idx, n0, B::ptrue());
+      B::g_w128(slab, idx + 1, n1, B::ptrue());
+    }
+  }
   // W (+)= Zd * conj(Zv), Zv given as (re,im)-interleaved dtype pairs (KfRegs layout)
   static FFC_FN void w_accum_z(float* slab, int tau, bool first, const typename BD::KfRegs& zv, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
@@ -280,6 +319,7 @@ struct Modes : Body<B, GEO, DT> {
       B::g_w128(slab, idx + 1, z, B::ptrue());
     }
   }
+  template <bool HALF = false>
   static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear) {
     const ConvArgs& a = d.c;
     BD::setup_tables(a.tab, a.t);
@@ -306,16 +346,15 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(av, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
-          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R, un);
+          BD::template load_inner<false>(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
-            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            BD::template tile_fwd<false>(un.wq * GEO::TPW + tt, R, un, re, im);
             z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
@@ -323,20 +362,21 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(ad, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
-          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R, un);
+          BD::template load_inner<false>(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             const int tau = un.wq * GEO::TPW + tt;
             typename BD::KfRegs zv;
             z_load(zs, tau, zv);
+            WOld wold;
+            w_load_old(slab, tau, it == 0, wold);
             A16 re, im;
-            BD::tile_fwd(tau, R, un, re, im);
-            w_accum_z(slab, tau, it == 0, zv, re, im);
+            BD::template tile_fwd<false>(tau, R, un, re, im);
+            w_update(slab, tau, wold, zv, re, im);
           }
         } else if (it == 0) {
 #pragma unroll 1
@@ -396,6 +436,7 @@ struct Modes : Body<B, GEO, DT> {
       }
     }
   }
+  template <bool HALF = false>
   static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear) {
     const ConvArgs& a = d.c;
     BD::setup_tables(a.tab, a.t);
@@ -426,16 +467,15 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(av, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
-          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R, un);
+          BD::template load_inner<false>(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
-            BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+            BD::template tile_fwd<false>(un.wq * GEO::TPW + tt, R, un, re, im);
             z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
@@ -443,12 +483,11 @@ struct Modes : Body<B, GEO, DT> {
         if (act) {
           BD::rows_in(ad, h, p, un);
           B::lds_fence();
-          if (GEO::S1 == 1 && 16 * GEO::Mi >= a.L) BD::template outer_stage<true, true>(a.L, un, a.s_fwd);
-          else BD::template outer_stage<true, false>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
         B::barrier();
         if (act) {
-          BD::load_inner(R, un);
+          BD::template load_inner<false>(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
             const int tau = un.wq * GEO::TPW + tt;
@@ -456,11 +495,13 @@ struct Modes : Body<B, GEO, DT> {
             z_load(zs, tau, zv);
             typename BD::KfRegs kf;
             BD::load_kf(a, h, tau, kf);
+            WOld wold;
+            w_load_old(slab, tau, it == 0, wold);
             A16 re, im;
-            BD::tile_fwd(tau, R, un, re, im);
-            w_accum_z(slab, tau, it == 0, zv, re, im);
+            BD::template tile_fwd<false>(tau, R, un, re, im);
+            w_update(slab, tau, wold, zv, re, im);
             kf_conj_mul(kf, re, im);
-            BD::tile_inv(a.s_inv, tau, R, un, re, im);
+            BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
           }
         } else if (it == 0) {
 #pragma unroll 1
@@ -468,10 +509,10 @@ struct Modes : Body<B, GEO, DT> {
         }
         B::barrier();
         if (act) {
-          BD::template outer_stage<false, false>(a.L, un);
+          BD::template outer_stage<false, HALF && GEO::S1 == 1>(a.L, un);
           B::lds_fence();
-          BD::rows_out(ao, h, p, un);
-          if (d.dpre) BD::rows_out(ap, h, p, un);
+          BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ao, h, p, un);
+          if (d.dpre) BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ap, h, p, un);
         }
       }
     } else {
