@@ -56,7 +56,7 @@ struct Body {
   using W4 = typename B::W4;     // MFMA operand: 8 x 16-bit per lane (4 dwords)
 
   struct Mat { W4 w[2][3]; };       // [K-step][Fr,Fi,-Fi]
-  struct CT16 { f32 re[16], im[16]; };
+  struct CT16 { A16 re, im; };          // 16 complex fp32 per lane, accumulator-shaped (packed-math friendly)
   struct Op { W4 r[2], i[2]; };     // complex MFMA data operand, 2 K-steps
 
   static FFC_FN void load_mat(Mat& m, const uint8_t* p, i32 lane) {
@@ -107,22 +107,10 @@ struct Body {
         o.i[ms][d] = B::template pack<DT>(im[8 * ms + 2 * d], im[8 * ms + 2 * d + 1]);
       }
   }
-  static FFC_FN void cmul(A16& re, A16& im, const CT16& t) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      f32 a = re[r], b = im[r];
-      re[r] = a * t.re[r] - b * t.im[r];
-      im[r] = a * t.im[r] + b * t.re[r];
-    }
-  }
-  static FFC_FN void cmul_conj(A16& re, A16& im, const CT16& t) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-      f32 a = re[r], b = im[r];
-      re[r] = a * t.re[r] + b * t.im[r];
-      im[r] = b * t.re[r] - a * t.im[r];
-    }
-  }
+  // element-wise complex multiplies on whole accumulator tuples: the device backend issues them as packed
+  // fp32 math (v_pk_mul_f32 / v_pk_fma_f32 on register pairs = half the VALU issue slots).
+  static FFC_FN void cmul(A16& re, A16& im, const CT16& t) { B::template cmul16<false>(re, im, t.re, t.im); }
+  static FFC_FN void cmul_conj(A16& re, A16& im, const CT16& t) { B::template cmul16<true>(re, im, t.re, t.im); }
   // Twiddle chain: t[i] = scale * cis(sign * 2*pi * ((base + off_i*step) mod N) / N) for the 8 row offsets
   // off = {0,1,2,3,8,9,10,11} an accumulator half holds: three v_sin/v_cos pairs (exact integer phases,
   // argument in revolutions) and seven complex multiplies instead of 8 sincos + per-element phase math.
@@ -703,6 +691,96 @@ struct Body {
     tile_inv(a.s_inv, tau, R, un, re, im);
   }
 
+  // Two tiles processed in lock-step: their chains are independent, so the MFMAs of one tile execute while
+  // the twiddle / conversion VALU work of the other one issues (a single tile alternates MFMA-only and
+  // VALU-only stretches and exposes the MFMA dependency latency each time).
+  static FFC_FN void kf_mul(const ConvArgs& a, const KfRegs& kf, A16& re, A16& im) {
+    CT16 k;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        k.re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+        k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
+      }
+    }
+    k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
+    cmul(re, im, k);
+  }
+  static FFC_FN void oi_twiddle(float s_inv, int tau, A16& re, A16& im) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
+    CT16 t;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const int sV = (16 * half) / GEO::N3;
+      i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
+      i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
+      f32 tr[8], ti[8];
+      chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
+#pragma unroll
+      for (int i = 0; i < 8; i++) { t.re[8 * half + i] = tr[i]; t.im[8 * half + i] = ti[i]; }
+    }
+    cmul(re, im, t);
+  }
+  static FFC_FN void tile_store(int tau, const InnerRegs& R, const A16& re, const A16& im) {
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      i32 off = R.woff[rq] + tau * (GEO::G * GEO::Mi * 2);
+      U2 vr, vi;
+      vr.x = B::template pack<DT>(re[4 * rq], re[4 * rq + 1]);
+      vr.y = B::template pack<DT>(re[4 * rq + 2], re[4 * rq + 3]);
+      vi.x = B::template pack<DT>(im[4 * rq], im[4 * rq + 1]);
+      vi.y = B::template pack<DT>(im[4 * rq + 2], im[4 * rq + 3]);
+      B::lds_w64(off, vr);
+      B::lds_w64(off + GEO::PLANE, vi);
+    }
+  }
+  static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un) {
+    static_assert(GEO::N3 == GEO::N2 && GEO::OUTER, "inner_tile2: fused sizes with one inner matrix");
+    const int tauB = tauA + 1;
+    KfRegs kfA, kfB;
+    load_kf(a, h, tauA, kfA);
+    load_kf(a, h, tauB, kfB);
+    Op opA, opB;
+    load_tile_op(tauA, opA, un, R);
+    load_tile_op(tauB, opB, un, R);
+    A16 reA, imA, reB, imB;
+    // stage a
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, true>(reA, imA, opA, R.F2);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, true>(reB, imB, opB, R.F2);
+    cmul(reA, imA, R.tw); to_op(reA, imA, opA);
+    // stage b (A) while B's twiddle issues
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, false>(reA, imA, opA, R.F2);
+    cmul(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, false>(reB, imB, opB, R.F2);
+    // (x) k_f, inverse stage b
+    kf_mul(a, kfA, reA, imA); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<true, true>(reA, imA, opA, R.F2);
+    kf_mul(a, kfB, reB, imB); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<true, true>(reB, imB, opB, R.F2);
+    // inverse twiddle, inverse stage a
+    cmul_conj(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<true, true>(reA, imA, opA, R.F2);
+    cmul_conj(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<true, true>(reB, imB, opB, R.F2);
+    // outer inverse twiddle + write back
+    oi_twiddle(a.s_inv, tauA, reA, imA);
+    tile_store(tauA, R, reA, imA);
+    oi_twiddle(a.s_inv, tauB, reB, imB);
+    tile_store(tauB, R, reB, imB);
+  }
+
   // Job loop of the fused sizes.  HALF (32-point outer digit, L <= N/2): only E rows < 16 carry input and
   // only result rows < 16 are stored, so half of the row traffic is skipped and the next pair's rows fit in
   // 32 VGPRs: they are prefetched right after phase A and written to E after rows_out of the current pair.
@@ -735,17 +813,21 @@ struct Body {
       if (act) {
         // no long-latency global load may be outstanding while a phase runs: vmcnt retires in order, so
         // anything the compiler spills would wait behind it.  k_f is prefetched one tile ahead only here.
-        KfRegs kf0;
-        load_kf(a, h, un.wq * GEO::TPW, kf0);
         InnerRegs R;
         load_inner(R, un);
+        if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
-        for (int tt = 0; tt < GEO::TPW; tt++) {
-          KfRegs kfn;
-          if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);
-          else if (PREFETCH && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
-          inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
-          kf0 = kfn;
+          for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2(a, h, un.wq * GEO::TPW + tt, R, un);
+        } else {
+          KfRegs kf0;
+          load_kf(a, h, un.wq * GEO::TPW, kf0);
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt++) {
+            KfRegs kfn;
+            if (tt + 1 < GEO::TPW) load_kf(a, h, un.wq * GEO::TPW + tt + 1, kfn);
+            inner_tile(a, un.wq * GEO::TPW + tt, R, un, kf0);
+            kf0 = kfn;
+          }
         }
       }
       FFC_TICK(3)

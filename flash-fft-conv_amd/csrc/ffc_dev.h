@@ -37,6 +37,14 @@ struct DevB {
   using A16 = f32x16;   // 16 consecutive VGPRs/AGPRs: the MFMA accumulator tuple
   using W4 = u32x4v;    // 4 consecutive VGPRs: one MFMA A/B operand
   static constexpr bool HAS_TR = true;
+  // element-wise complex multiply of two accumulator tuples (x (x) t or x (x) conj t): whole-vector fp32 ops,
+  // which gfx950 legalises to v_pk_mul_f32 / v_pk_fma_f32 on aligned register pairs
+  template <bool CONJ> static FFC_FN void cmul16(A16& re, A16& im, const A16& tr, const A16& ti) {
+    const A16 a = re, b = im;
+    if (!CONJ) { re = a * tr - b * ti; im = a * ti + b * tr; }
+    else { re = a * tr + b * ti; im = b * tr - a * ti; }
+  }
+  static FFC_FN A16 a16_scale(const A16& a, float s) { return a * s; }
   static FFC_FN A16 a16_zero() { A16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
   static FFC_FN W4 w4(u32 a, u32 b, u32 c, u32 e) { W4 v = {a, b, c, e}; return v; }
 

@@ -66,6 +66,14 @@ struct SimB {
   struct U4 { u32 x, y, z, w; };
   struct A16 { f32 v[16]; f32& operator[](int i) { return v[i]; } const f32& operator[](int i) const { return v[i]; } };
   struct W4 { u32 v[4]; u32& operator[](int i) { return v[i]; } const u32& operator[](int i) const { return v[i]; } };
+  template <bool CONJ> static void cmul16(A16& re, A16& im, const A16& tr, const A16& ti) {
+    for (int r = 0; r < 16; r++) {
+      f32 a = re[r], b = im[r];
+      if (!CONJ) { re[r] = a * tr[r] - b * ti[r]; im[r] = a * ti[r] + b * tr[r]; }
+      else { re[r] = a * tr[r] + b * ti[r]; im[r] = b * tr[r] - a * ti[r]; }
+    }
+  }
+  static A16 a16_scale(const A16& a, float s) { A16 r; for (int i = 0; i < 16; i++) r[i] = a[i] * f32(s); return r; }
   static A16 a16_zero() { A16 z; for (int i = 0; i < 16; i++) z.v[i] = f32(0.f); return z; }
   static W4 w4(const u32& a, const u32& b, const u32& c, const u32& e) { W4 v; v.v[0] = a; v.v[1] = b; v.v[2] = c; v.v[3] = e; return v; }
   static bool HAS_TR;
