@@ -6,6 +6,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib")
 HIP_SO = os.path.join(LIB, "libflashfftconv_hip.so")
 SIM_SO = os.path.join(LIB, "libffcsim.so")
+# -fno-slp-vectorize: packed fp32 math is written explicitly where it pays; auto-formed pairs cost v_mov shuffles.
+# --amdgpu-mfma-vgpr-form: MFMA results stay in architectural VGPRs; the accumulation registers a0..a127 are
+#   addressed by hand in the backward kernels (dk_f partial sums) and must never be picked by the allocator.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "--amdgpu-mfma-vgpr-form", "-fPIC"]
+AGPR_CHECKED = ["ffc_k_dkf.hip"]     # translation units whose device code is scanned by check_agpr()
 HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
@@ -18,6 +23,46 @@ def _stale(target, srcs):
     return any(os.path.getmtime(d) > t for d in deps if os.path.isfile(d))
 
 
+def check_agpr(asm_path):
+    """The backward kernels keep state in a0..a127 through explicit v_accvgpr_read/write (csrc/ffc_dev.h,
+    agpr_get/agpr_set).  Any other reference to an accumulation register means the compiler allocated one
+    for its own use and would clobber that state: fail the build."""
+    import re
+    from collections import Counter
+    mine = re.compile(r"^\s*v_accvgpr_(read_b32 v\d+, a(\d+)|write_b32 a(\d+), (?:v\d+|0))\s*$")
+    areg = re.compile(r"\ba\[\d+:\d+\]|\ba\d+\b")
+    kernel, reads, writes, bad = None, Counter(), Counter(), []
+
+    def close():
+        # every accumulator is zeroed + updated (2 writes) and read for the update + the final store (2 reads);
+        # any other count is a compiler spill into the same register
+        for idx in set(reads) | set(writes):
+            if reads[idx] != 2 or writes[idx] != 2:
+                bad.append(f"{kernel}: a{idx} read {reads[idx]}x written {writes[idx]}x")
+        reads.clear(); writes.clear()
+
+    with open(asm_path) as fh:
+        for line in fh:
+            t = line.split(";")[0].rstrip()
+            m = re.match(r"^(_Z\w+):", t)
+            if m:
+                close(); kernel = m.group(1)
+                continue
+            if not t.strip() or t.lstrip().startswith("."):
+                continue
+            if areg.search(t):
+                mm = mine.match(t)
+                if not mm:
+                    bad.append(f"{kernel}: {t.strip()}")
+                elif mm.group(2) is not None:
+                    reads[mm.group(2)] += 1
+                else:
+                    writes[mm.group(3)] += 1
+    close()
+    if bad:
+        raise RuntimeError(f"{asm_path}: compiler-allocated accumulation registers ({len(bad)} findings), e.g. {bad[:3]}")
+
+
 def build_hip(force=False, verbose=False):
     """Compile every translation unit for gfx950 in parallel, then link the shared library."""
     from concurrent.futures import ThreadPoolExecutor
@@ -28,19 +73,25 @@ def build_hip(force=False, verbose=False):
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "flashfftconv_hip.h")))
 
-    def compile_one(f):
+    def compile_one(job):
+        f, want_asm = job
         src = os.path.join(CSRC, f)
-        obj = os.path.join(obj_dir, f + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-c", "-x", "hip", src, "-o", obj]
+        out = os.path.join(obj_dir, f + (".s" if want_asm else ".o"))
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time):
+            cmd = [hipcc] + HIP_FLAGS + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            return obj, True
-        return obj, False
+            if want_asm:
+                check_agpr(out)
+            return out, True
+        return out, False
 
-    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
-        res = list(ex.map(compile_one, HIP_SRCS))
+    # the checked translation units are compiled twice (object + device assembly for check_agpr), side by side
+    jobs = [(f, False) for f in HIP_SRCS] + [(f, True) for f in AGPR_CHECKED]
+    jobs.sort(key=lambda j: j[0] not in AGPR_CHECKED)          # longest first
+    with ThreadPoolExecutor(max_workers=min(10, os.cpu_count() or 4)) as ex:
+        res = [r for r, j in zip(ex.map(compile_one, jobs), jobs) if not j[1]]
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not os.path.exists(HIP_SO):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)

@@ -64,14 +64,15 @@ struct Body {
     for (int q = 0; q < 6; q++) {
       U4 v = B::g_r128(p, lane + q * 64);
       m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
+      B::pin(m.w[q / 3][q % 3]);
     }
   }
   static FFC_FN void load_ct16(CT16& c, const uint8_t* p, i32 lane) {
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
       U4 v = B::g_r128(p, lane + rr * 64);
-      c.re[2 * rr] = B::as_f32(v.x); c.im[2 * rr] = B::as_f32(v.y);
-      c.re[2 * rr + 1] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
+      c.re[2 * rr] = B::as_f32(v.x); c.re[2 * rr + 1] = B::as_f32(v.y);
+      c.im[2 * rr] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
     }
   }
   // acc += M (x) data.  AFORM: data is the MFMA A operand (its lane index moves to registers,
@@ -187,6 +188,7 @@ struct Body {
     for (int q = 0; q < 6; q++) {
       U4 v = B::lds_r128(lane * 16 + (off + q * 1024));
       m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
+      B::pin(m.w[q / 3][q % 3]);
     }
   }
   static FFC_FN void lds_ct16(CT16& c, int off) {
@@ -194,8 +196,19 @@ struct Body {
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
       U4 v = B::lds_r128(lane * 16 + (off + rr * 1024));
-      c.re[2 * rr] = B::as_f32(v.x); c.im[2 * rr] = B::as_f32(v.y);
-      c.re[2 * rr + 1] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
+      c.re[2 * rr] = B::as_f32(v.x); c.re[2 * rr + 1] = B::as_f32(v.y);
+      c.im[2 * rr] = B::as_f32(v.z); c.im[2 * rr + 1] = B::as_f32(v.w);
+    }
+  }
+  // x (x) tab (or conj tab) with the table streamed from LDS two rows at a time (4 transient registers
+  // instead of a 32-register CT16)
+  template <bool CONJ>
+  static FFC_FN void cmul_lds(A16& re, A16& im, int off) {
+    const i32 lane = B::lane();
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) {
+      U4 v = B::lds_r128(lane * 16 + (off + rr * 1024));
+      B::template cmul2<CONJ>(re, im, 2 * rr, B::as_f32(v.x), B::as_f32(v.y), B::as_f32(v.z), B::as_f32(v.w));
     }
   }
   // t[r] *= tab[hi][r] where tab is a [2][16] complex f32 LDS table (lane-uniform per half-wave)
@@ -401,7 +414,89 @@ struct Body {
   // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
   // HALF: input rows n1 >= 16 are all zero (L <= 16*Mi, 32-point outer digit) -> one K-step.
   template <bool FWD, bool HALF>
-  static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f) {
+  static FFC_FN void outer_stage_tile(int L, Unit un, float s_fwd = 1.0f) {
+    const i32 lane = B::opaque(B::lane());
+    const int w = un.wq;
+    const i32 j = lane & 31, hi = lane >> 5;
+    constexpr int ms_lim = (FWD && HALF) ? 1 : 2;
+    // tile-local row R = 4*hi + c (c a compile-time constant with bit 2 clear) -> column set
+    // s1 = c / N1 and E row rw = c % N1 + 4*hi.  e_off = row term + swizzled column term, so every
+    // access below is (one of S1 lane-dependent bases) + immediate.
+    i32 colb[GEO::S1];
+#pragma unroll
+    for (int s = 0; s < GEO::S1; s++)
+      colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
+    Mat F1;
+    lds_mat(F1, GEO::L_F1);
+#pragma unroll 1
+    for (int t = 0; t < 4; t++) {          // the 4 column tiles of this wave; a runtime loop bounds the live ranges
+      // operand halves come straight from 16-bit LDS reads (element t of each 8-byte chunk) and the results go
+      // back as 16-bit stores: no word stash across tiles, no shift/mask work to split or merge dwords
+      i32 colt[GEO::S1];
+#pragma unroll
+      for (int s = 0; s < GEO::S1; s++) colt[s] = colb[s] + 2 * t;
+      Op op;
+#pragma unroll
+      for (int ms = 0; ms < 2; ms++) {
+        if (ms >= ms_lim) continue;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          u32 vr[2], vi[2];
+#pragma unroll
+          for (int hf = 0; hf < 2; hf++) {
+            const int e = 2 * d + hf;
+            const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
+            const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+            i32 off = colt[s1] + rwc * (GEO::Mi * 2);
+            vr[hf] = B::lds_r16(off); vi[hf] = B::lds_r16(off + GEO::PLANE);
+            if (FWD) {
+              pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
+              vr[hf] = B::sel(ok, vr[hf], B::uconst(0));
+              vi[hf] = B::sel(ok, vi[hf], B::uconst(0));
+            }
+          }
+          op.r[ms][d] = vr[0] | (vr[1] << 16);
+          op.i[ms][d] = vi[0] | (vi[1] << 16);
+        }
+      }
+      A16 re, im;
+      re = B::a16_zero(); im = B::a16_zero();
+      cmm<!FWD, false>(re, im, op, F1, ms_lim);
+      if (FWD) {
+        // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
+#pragma unroll
+        for (int half = 0; half < 2; half++) {     // accumulator registers 0-7 / 8-15 (rows +16)
+          const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
+          i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + t);
+          i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
+          f32 tr[8], ti[8];
+          chain8(m * k0, m, -1.0f, s_fwd, tr, ti);
+#pragma unroll
+          for (int i = 0; i < 8; i += 2)
+            B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
+        u32 vr = B::template pack<DT>(re[r], re[r + 1]);
+        u32 vi = B::template pack<DT>(im[r], im[r + 1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int c = ((r + q) & 3) + 8 * ((r + q) >> 2);
+          const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+          i32 off = colt[s1] + rwc * (GEO::Mi * 2);
+          B::lds_w16(off, q ? (vr >> 16) : vr);
+          B::lds_w16(off + GEO::PLANE, q ? (vi >> 16) : vi);
+        }
+      }
+    }
+  }
+
+  // tile-pair variant: 32-bit LDS accesses shared by two column tiles (fewer LDS instructions, more VALU
+  // split/merge work and registers)
+  template <bool FWD, bool HALF>
+  static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
@@ -491,6 +586,14 @@ struct Body {
     }
   }
 
+  // The forward/dx kernels take the tile-pair variant (fastest); the backward kernels, which run on the
+  // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
+  template <bool FWD, bool HALF>
+  static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f) {
+    if constexpr (B::LEAN_OUTER) outer_stage_tile<FWD, HALF>(L, un, s_fwd);
+    else outer_stage_pair<FWD, HALF>(L, un, s_fwd);
+  }
+
   // ------------------------------------------------------------------ phase B (inner tile)
   // per-lane LDS offsets of tile 0 (tile tau adds tau*G rows): operand reads [K-step][rho] and write-back [rq]
   struct InnerRegs { Mat F2; CT16 tw; i32 roff[2][2]; i32 woff[4]; };
@@ -531,6 +634,8 @@ struct Body {
           op.r[ms][2 * rho] = vr.x; op.r[ms][2 * rho + 1] = vr.y;
           op.i[ms][2 * rho] = vi.x; op.i[ms][2 * rho + 1] = vi.y;
         }
+#pragma unroll
+      for (int ms = 0; ms < 2; ms++) { B::pin(op.r[ms]); B::pin(op.i[ms]); }
     } else {
       const i32 lane = B::opaque(B::lane());
       const i32 c = lane & 31, hi = lane >> 5;
@@ -569,9 +674,7 @@ struct Body {
     if constexpr (TWR) {
       cmul(re, im, R.tw);
     } else {
-      CT16 tw;
-      lds_ct16(tw, GEO::L_TW);
-      cmul(re, im, tw);
+      cmul_lds<false>(re, im, GEO::L_TW);
     }
     to_op(re, im, op);
     // stage b: contract n3 (B-form) -> [V'=(sV,k3) regs][U' lanes]
@@ -601,15 +704,11 @@ struct Body {
       cmm<true, true>(re, im, op, R.F2);
     }
     if constexpr (GEO::TW2_SEP) {
-      CT16 tw2;
-      lds_ct16(tw2, GEO::L_TW2);
-      cmul(re, im, tw2);
+      cmul_lds<false>(re, im, GEO::L_TW2);
     } else if constexpr (TWR) {
       cmul_conj(re, im, R.tw);
     } else {
-      CT16 tw;
-      lds_ct16(tw, GEO::L_TW);
-      cmul_conj(re, im, tw);
+      cmul_lds<true>(re, im, GEO::L_TW);
     }
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]
@@ -641,12 +740,8 @@ struct Body {
         f32 tr[8], ti[8];
         chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);     // conj(W^{m k1}) = cos + i sin
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int r = 8 * half + i;
-          f32 x = re[r], y = im[r];
-          re[r] = x * tr[i] - y * ti[i];
-          im[r] = x * ti[i] + y * tr[i];
-        }
+        for (int i = 0; i < 8; i += 2)
+          B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
       }
     }
     // write back in place: lane <-> (sU,n2), regs <-> (sV,n3); r&3 = 4 consecutive n3
@@ -712,7 +807,6 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
-    CT16 t;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int sV = (16 * half) / GEO::N3;
@@ -721,9 +815,9 @@ struct Body {
       f32 tr[8], ti[8];
       chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
 #pragma unroll
-      for (int i = 0; i < 8; i++) { t.re[8 * half + i] = tr[i]; t.im[8 * half + i] = ti[i]; }
+      for (int i = 0; i < 8; i += 2)
+        B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
     }
-    cmul(re, im, t);
   }
   static FFC_FN void tile_store(int tau, const InnerRegs& R, const A16& re, const A16& im) {
 #pragma unroll

@@ -34,6 +34,7 @@ struct DevB {
   using pred = bool;
   struct U2 { u32 x, y; };
   struct U4 { u32 x, y, z, w; };
+  static constexpr bool LEAN_OUTER = false;
   using A16 = f32x16;   // 16 consecutive VGPRs/AGPRs: the MFMA accumulator tuple
   using W4 = u32x4v;    // 4 consecutive VGPRs: one MFMA A/B operand
   static constexpr bool HAS_TR = true;
@@ -43,6 +44,46 @@ struct DevB {
     const A16 a = re, b = im;
     if (!CONJ) { re = a * tr - b * ti; im = a * ti + b * tr; }
     else { re = a * tr + b * ti; im = b * tr - a * ti; }
+  }
+  using F2 = f32x2;
+  static FFC_FN F2 f2(f32 a, f32 b) { F2 v = {a, b}; return v; }
+  static FFC_FN f32 f2_lo(F2 v) { return v.x; }
+  static FFC_FN f32 f2_hi(F2 v) { return v.y; }
+  // (wr, wi) += x[r0..r0+1] (x) conj z : packed fp32 math on register pairs
+  static FFC_FN void cmac2_conj(F2& wr, F2& wi, const A16& a, const A16& b, int r0, F2 zr, F2 zi) {
+    const F2 a2 = {a[r0], a[r0 + 1]}, b2 = {b[r0], b[r0 + 1]};
+    wr = wr + (a2 * zr + b2 * zi);
+    wi = wi + (b2 * zr - a2 * zi);
+  }
+  // Accumulation registers a0..a127 addressed by number (see Modes::WAcc).  The kernel marks them used once
+  // (agpr_reserve) so that the kernel descriptor allocates them; the compiler itself never places values there
+  // (MFMAs are kept in VGPR form, build flag -mllvm --amdgpu-mfma-vgpr-form; build.py checks the disassembly).
+#define FFC_A8(b) "a" #b "0", "a" #b "1", "a" #b "2", "a" #b "3", "a" #b "4", "a" #b "5", "a" #b "6", "a" #b "7", "a" #b "8", "a" #b "9"
+  static FFC_FN void agpr_reserve() {
+    asm volatile("; a0..a127 hold the dk_f partial sums"
+                 ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", FFC_A8(1), FFC_A8(2), FFC_A8(3), FFC_A8(4),
+                     FFC_A8(5), FFC_A8(6), FFC_A8(7), FFC_A8(8), FFC_A8(9), FFC_A8(10), FFC_A8(11), "a120", "a121", "a122",
+                     "a123", "a124", "a125", "a126", "a127");
+  }
+#undef FFC_A8
+  template <int I> static FFC_FN f32 agpr_get() {
+    f32 x;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(x) : "n"(I));
+    return x;
+  }
+  template <int I> static FFC_FN void agpr_set(f32 x) { asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"n"(I), "v"(x)); }
+  // keep a load-defined MFMA operand in architectural VGPRs (the allocator may otherwise place it in the
+  // accumulation registers, which hold the dk_f partial sums in the backward kernels)
+  static FFC_FN void pin(W4& x) { asm("" : "+v"(x)); }
+  static FFC_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+  // rows r0, r0+1 of (re,im) times (t0,t1) (or its conjugate): one packed mul + one packed fma per output pair
+  template <bool CONJ>
+  static FFC_FN void cmul2(A16& re, A16& im, int r0, f32 tr0, f32 tr1, f32 ti0, f32 ti1) {
+    const f32x2 a = {re[r0], re[r0 + 1]}, b = {im[r0], im[r0 + 1]}, tr = {tr0, tr1}, ti = {ti0, ti1};
+    f32x2 x, y;
+    if (!CONJ) { x = a * tr - b * ti; y = a * ti + b * tr; }
+    else { x = a * tr + b * ti; y = b * tr - a * ti; }
+    re[r0] = x.x; re[r0 + 1] = x.y; im[r0] = y.x; im[r0 + 1] = y.y;
   }
   static FFC_FN A16 a16_scale(const A16& a, float s) { return a * s; }
   static FFC_FN A16 a16_zero() { A16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
@@ -64,6 +105,7 @@ struct DevB {
     if (p) *(uint4*)(ffc_smem + off) = make_uint4(v.x, v.y, v.z, v.w);
   }
   static FFC_FN U4 lds_r128(i32 off) { uint4 v = *(const uint4*)(ffc_smem + off); return U4{v.x, v.y, v.z, v.w}; }
+  static FFC_FN void lds_w16(i32 off, u32 v) { *(uint16_t*)(ffc_smem + off) = (uint16_t)v; }
   static FFC_FN u32 lds_r32(i32 off) { return *(const uint32_t*)(ffc_smem + off); }
   static FFC_FN u32 lds_r16(i32 off) { return *(const uint16_t*)(ffc_smem + off); }
   static FFC_FN U2 lds_r64_tr(i32 off) {
@@ -156,6 +198,14 @@ __device__ __forceinline__ bool map_block(int H, int nchunk, int* h, int* chunk)
   *chunk = s % nchunk;
   return *h < H;
 }
+
+// DevB with an opaque lane id: every use site re-derives its lane-dependent values, nothing lane-derived is
+// hoisted out of the per-pair loop.  The backward kernels run on a 128-VGPR budget (see Modes::WAcc); hoisted
+// invariants there would overflow into the accumulation registers that hold the dk_f partial sums.
+struct DevBO : DevB {
+  static constexpr bool LEAN_OUTER = true;     // per-tile outer stages (fewer registers)
+  static FFC_FN i32 lane() { int x = (int)(threadIdx.x & 63); asm volatile("" : "+v"(x)); return x; }
+};
 
 }  // namespace ffc
 

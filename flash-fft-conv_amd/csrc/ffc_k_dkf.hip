@@ -2,24 +2,43 @@
 #include "ffc_dev.h"
 using namespace ffc;
 
+// Fused sizes keep the dk_f partial sums in a0..a127 (Modes::WAcc): the architectural half of the unified
+// register file (128 VGPRs at 2 waves per SIMD) is what the allocator gets.
 template <class GEO, int DT, bool HALF>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel(DkfArgs d) {
+__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void dkf_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
+  Modes<DevBO, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
+}
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel_small(DkfArgs d) {   // single-tile sizes (N <= 1024)
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevB, GEO, DT>::template dkf<false>(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct DkfLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
-    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= d.c.L) {
-      static int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+    const dim3 grid(hpad * d.c.nchunk), block(GEO::WGW * 64);
+    if constexpr (!GEO::OUTER) {
+      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((dkf_kernel<GEO, DT, true>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+      hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, GEO::LDS_BYTES, st, d);
     } else {
-      static int rc = ffc_set_lds(dkf_kernel<GEO, DT, false>, GEO::LDS_BYTES);
-      if (rc) return rc;
-      hipLaunchKernelGGL((dkf_kernel<GEO, DT, false>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+      bool half = false;
+      if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;
+      if (half) {
+        if constexpr (GEO::S1 == 1) {
+          static int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((dkf_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
+        }
+      } else {
+        static int rc = ffc_set_lds(dkf_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((dkf_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
+      }
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("dkf_kernel launch: ") + hipGetErrorString(e));
@@ -27,23 +46,40 @@ struct DkfLaunch {
 };
 
 template <class GEO, int DT, bool HALF>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel(DkfArgs d) {
+__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_kernel(DkfArgs d) {
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+  Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+}
+template <class GEO, int DT>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel_small(DkfArgs d) {
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevB, GEO, DT>::template bwd<false>(d, h, chunk, blockIdx.x);
 }
 template <class GEO, int DT>
 struct BwdLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
-    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= d.c.L) {
-      static int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+    const dim3 grid(hpad * d.c.nchunk), block(GEO::WGW * 64);
+    if constexpr (!GEO::OUTER) {
+      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, GEO::LDS_BYTES, st, d);
     } else {
-      static int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
-      if (rc) return rc;
-      hipLaunchKernelGGL((bwd_kernel<GEO, DT, false>), dim3(hpad * d.c.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, d);
+      bool half = false;
+      if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;
+      if (half) {
+        if constexpr (GEO::S1 == 1) {
+          static int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
+        }
+      } else {
+        static int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((bwd_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
+      }
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_kernel launch: ") + hipGetErrorString(e));

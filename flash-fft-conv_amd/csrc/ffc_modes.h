@@ -52,6 +52,9 @@ struct DkArgs {
   int fast;
 };
 
+#ifndef FFC_WREG
+#define FFC_WREG 4
+#endif
 template <class B, class GEO, int DT>
 struct Modes : Body<B, GEO, DT> {
   using BD = Body<B, GEO, DT>;
@@ -319,6 +322,112 @@ struct Modes : Body<B, GEO, DT> {
       B::g_w128(slab, idx + 1, z, B::ptrue());
     }
   }
+  // Register-resident partial sums.  A wave owns its TPW tiles of W for the whole chunk: 4 tiles x 32 fp32
+  // per lane = 128 registers, which live in the accumulation half (AGPRs a0..a127) of the unified register
+  // file, addressed explicitly by the backend (agpr_get / agpr_set).  They are invisible to the register
+  // allocator, which keeps the architectural half (128 VGPRs) for the transforms; the slab is written once
+  // per chunk instead of read-modified-written for every pair.  FFC_WREG=0 selects the slab path.
+  using F2 = typename B::F2;       // fp32 pair = one packed-math register pair
+  static constexpr int WREG = FFC_WREG < GEO::TPW ? 0 : GEO::TPW;
+  struct WAcc { int unused; };
+  template <int I0, int N>
+  static FFC_FN void w_acc_zero_range() {
+    if constexpr (N == 1) B::template agpr_set<I0>(B::fconst(0.f));
+    else { w_acc_zero_range<I0, N / 2>(); w_acc_zero_range<I0 + N / 2, N - N / 2>(); }
+  }
+  static FFC_FN void w_acc_zero(WAcc&) {
+    if constexpr (WREG > 0) { B::agpr_reserve(); w_acc_zero_range<0, 32 * WREG>(); }
+  }
+  // accumulator a[32T + 16*part + r]: part 0 = re, 1 = im, r = accumulator row slot
+  template <int T, int RQ>
+  static FFC_FN void w_acc_quarter(const U4& z, const A16& re, const A16& im) {
+    u32 wv[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      F2 zr = B::f2(B::template unpack_lo<DT>(wv[2 * j]), B::template unpack_lo<DT>(wv[2 * j + 1]));
+      F2 zi = B::f2(B::template unpack_hi<DT>(wv[2 * j]), B::template unpack_hi<DT>(wv[2 * j + 1]));
+      if (j == 0) {
+        constexpr int R0 = 4 * RQ;
+        F2 wr = B::f2(B::template agpr_get<32 * T + R0>(), B::template agpr_get<32 * T + R0 + 1>());
+        F2 wi = B::f2(B::template agpr_get<32 * T + 16 + R0>(), B::template agpr_get<32 * T + 16 + R0 + 1>());
+        B::cmac2_conj(wr, wi, re, im, R0, zr, zi);
+        B::template agpr_set<32 * T + R0>(B::f2_lo(wr)); B::template agpr_set<32 * T + R0 + 1>(B::f2_hi(wr));
+        B::template agpr_set<32 * T + 16 + R0>(B::f2_lo(wi)); B::template agpr_set<32 * T + 16 + R0 + 1>(B::f2_hi(wi));
+      } else {
+        constexpr int R0 = 4 * RQ + 2;
+        F2 wr = B::f2(B::template agpr_get<32 * T + R0>(), B::template agpr_get<32 * T + R0 + 1>());
+        F2 wi = B::f2(B::template agpr_get<32 * T + 16 + R0>(), B::template agpr_get<32 * T + 16 + R0 + 1>());
+        B::cmac2_conj(wr, wi, re, im, R0, zr, zi);
+        B::template agpr_set<32 * T + R0>(B::f2_lo(wr)); B::template agpr_set<32 * T + R0 + 1>(B::f2_hi(wr));
+        B::template agpr_set<32 * T + 16 + R0>(B::f2_lo(wi)); B::template agpr_set<32 * T + 16 + R0 + 1>(B::f2_hi(wi));
+      }
+    }
+  }
+  template <int T>
+  static FFC_FN void w_acc_tile(const typename BD::KfRegs& zv, const A16& re, const A16& im) {
+    w_acc_quarter<T, 0>(zv.v[0], re, im);
+    w_acc_quarter<T, 1>(zv.v[1], re, im);
+    w_acc_quarter<T, 2>(zv.v[2], re, im);
+    w_acc_quarter<T, 3>(zv.v[3], re, im);
+  }
+  template <int T, int RQ>
+  static FFC_FN void w_acc_store_q(float* slab, int tau0, i32 hi, i32 c) {
+    i32 idx = ((hi + ((tau0 + T) * 8 + 2 * RQ)) * 32 + c) * 2;
+    constexpr int A0 = 32 * T + 4 * RQ;
+    U4 n0, n1;
+    n0.x = B::as_u32(B::template agpr_get<A0>());     n0.y = B::as_u32(B::template agpr_get<A0 + 16>());
+    n0.z = B::as_u32(B::template agpr_get<A0 + 1>()); n0.w = B::as_u32(B::template agpr_get<A0 + 17>());
+    n1.x = B::as_u32(B::template agpr_get<A0 + 2>()); n1.y = B::as_u32(B::template agpr_get<A0 + 18>());
+    n1.z = B::as_u32(B::template agpr_get<A0 + 3>()); n1.w = B::as_u32(B::template agpr_get<A0 + 19>());
+    B::g_w128(slab, idx, n0, B::ptrue());
+    B::g_w128(slab, idx + 1, n1, B::ptrue());
+  }
+  template <int T>
+  static FFC_FN void w_acc_store_t(float* slab, int tau0, i32 hi, i32 c) {
+    w_acc_store_q<T, 0>(slab, tau0, hi, c); w_acc_store_q<T, 1>(slab, tau0, hi, c);
+    w_acc_store_q<T, 2>(slab, tau0, hi, c); w_acc_store_q<T, 3>(slab, tau0, hi, c);
+  }
+  static FFC_FN void w_acc_store(float* slab, int tau0, const WAcc&) {
+    if constexpr (WREG > 0) {
+      const i32 lane = B::opaque(B::lane());
+      const i32 c = lane & 31, hi = lane >> 5;
+      w_acc_store_t<0>(slab, tau0, hi, c); w_acc_store_t<1>(slab, tau0, hi, c);
+      w_acc_store_t<2>(slab, tau0, hi, c); w_acc_store_t<3>(slab, tau0, hi, c);
+    }
+  }
+  // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
+  // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
+  // accumulator registers are addressed statically.
+  template <bool WITH_DX>
+  static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W) {
+#pragma unroll 1
+    for (int tt = 0; tt < GEO::TPW; tt++) {
+      const int tau = un.wq * GEO::TPW + tt;
+      typename BD::KfRegs zv;
+      z_load(zs, tau, zv);
+      typename BD::KfRegs kf;
+      if constexpr (WITH_DX) BD::load_kf(a, h, tau, kf);
+      A16 re, im;
+      if (WREG >= GEO::TPW || tt < WREG) {
+        BD::template tile_fwd<false>(tau, R, un, re, im);
+        switch (tt) {
+          case 0: if constexpr (WREG > 0) w_acc_tile<0>(zv, re, im); break;
+          case 1: if constexpr (WREG > 1) w_acc_tile<1>(zv, re, im); break;
+          case 2: if constexpr (WREG > 2) w_acc_tile<2>(zv, re, im); break;
+          default: if constexpr (WREG > 3) w_acc_tile<3>(zv, re, im); break;
+        }
+      } else {
+        WOld wold;
+        w_load_old(slab, tau, first, wold);
+        BD::template tile_fwd<false>(tau, R, un, re, im);
+        w_update(slab, tau, wold, zv, re, im);
+      }
+      if constexpr (WITH_DX) {
+        kf_conj_mul(kf, re, im);
+        BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
+      }
+    }
+  }
   template <bool HALF = false>
   static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear) {
     const ConvArgs& a = d.c;
@@ -339,6 +448,8 @@ struct Modes : Body<B, GEO, DT> {
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
       uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
+      WAcc W;
+      w_acc_zero(W);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -367,23 +478,14 @@ struct Modes : Body<B, GEO, DT> {
         B::barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
-#pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) {
-            const int tau = un.wq * GEO::TPW + tt;
-            typename BD::KfRegs zv;
-            z_load(zs, tau, zv);
-            WOld wold;
-            w_load_old(slab, tau, it == 0, wold);
-            A16 re, im;
-            BD::template tile_fwd<false>(tau, R, un, re, im);
-            w_update(slab, tau, wold, zv, re, im);
-          }
+          bwd_tiles<false>(a, h, un, R, zs, slab, it == 0, W);
         } else if (it == 0) {
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
+          for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
         B::barrier();
       }
+      w_acc_store(slab, un.wq * GEO::TPW, W);
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
@@ -423,18 +525,17 @@ struct Modes : Body<B, GEO, DT> {
   //           dv = iFFT(Z_d conj(k_f)); du = dv * pregate; dpre = dv * u.
   // (reference: kernels_bf16/monarch_cuda_*_bwd_kernel_bf16.h compute the same three transforms)
   static FFC_FN void kf_conj_mul(const typename BD::KfRegs& kf, A16& re, A16& im) {
+    typename BD::CT16 k;
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
       u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]);
-        int r = 4 * rq + q;
-        f32 x = re[r], y = im[r];
-        re[r] = x * kr + y * ki;
-        im[r] = y * kr - x * ki;
+        k.re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+        k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
       }
     }
+    BD::cmul_conj(re, im, k);
   }
   template <bool HALF = false>
   static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear) {
@@ -460,6 +561,8 @@ struct Modes : Body<B, GEO, DT> {
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
       uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
+      WAcc W;
+      w_acc_zero(W);
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -488,24 +591,10 @@ struct Modes : Body<B, GEO, DT> {
         B::barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
-#pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) {
-            const int tau = un.wq * GEO::TPW + tt;
-            typename BD::KfRegs zv;
-            z_load(zs, tau, zv);
-            typename BD::KfRegs kf;
-            BD::load_kf(a, h, tau, kf);
-            WOld wold;
-            w_load_old(slab, tau, it == 0, wold);
-            A16 re, im;
-            BD::template tile_fwd<false>(tau, R, un, re, im);
-            w_update(slab, tau, wold, zv, re, im);
-            kf_conj_mul(kf, re, im);
-            BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
-          }
+          bwd_tiles<true>(a, h, un, R, zs, slab, it == 0, W);
         } else if (it == 0) {
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
+          for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
         B::barrier();
         if (act) {
@@ -515,6 +604,7 @@ struct Modes : Body<B, GEO, DT> {
           if (d.dpre) BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ap, h, p, un);
         }
       }
+      w_acc_store(slab, un.wq * GEO::TPW, W);
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;

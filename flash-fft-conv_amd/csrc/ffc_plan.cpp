@@ -134,9 +134,9 @@ void fill_ctab16(uint8_t* dst, F fn) {
     for (int r = 0; r < 16; r++) {
       double re, im;
       fn(lane, r, &re, &im);
-      int rr = r >> 1, o = (r & 1) * 2;
+      int rr = r >> 1, o = r & 1;          // per lane and row pair: (re0, re1, im0, im1) = packed-math operands
       w[(rr * 64 + lane) * 4 + o] = (float)re;
-      w[(rr * 64 + lane) * 4 + o + 1] = (float)im;
+      w[(rr * 64 + lane) * 4 + o + 2] = (float)im;
     }
 }
 

@@ -53,11 +53,13 @@ struct WgCtx {
 };
 static thread_local WgCtx* g_wg = nullptr;
 static thread_local int g_wave = 0;
+static thread_local Vec<float> g_agpr[128];   // per-wave accumulation registers (DevB: a0..a127)
 
 static inline float dt_to_f32(int DT, uint16_t h) { return DT == DT_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
 static inline uint16_t f32_to_dt(int DT, float f) { return DT == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
 
 struct SimB {
+  static constexpr bool LEAN_OUTER = false;
   using f32 = Vec<float>;
   using i32 = Vec<int>;
   using u32 = Vec<uint32_t>;
@@ -71,6 +73,30 @@ struct SimB {
       f32 a = re[r], b = im[r];
       if (!CONJ) { re[r] = a * tr[r] - b * ti[r]; im[r] = a * ti[r] + b * tr[r]; }
       else { re[r] = a * tr[r] + b * ti[r]; im[r] = b * tr[r] - a * ti[r]; }
+    }
+  }
+  struct F2 { f32 x, y; };
+  static F2 f2(const f32& a, const f32& b) { F2 v; v.x = a; v.y = b; return v; }
+  static f32 f2_lo(const F2& v) { return v.x; }
+  static f32 f2_hi(const F2& v) { return v.y; }
+  static void cmac2_conj(F2& wr, F2& wi, const A16& a, const A16& b, int r0, const F2& zr, const F2& zi) {
+    wr.x = wr.x + (a[r0] * zr.x + b[r0] * zi.x);
+    wr.y = wr.y + (a[r0 + 1] * zr.y + b[r0 + 1] * zi.y);
+    wi.x = wi.x + (b[r0] * zr.x - a[r0] * zi.x);
+    wi.y = wi.y + (b[r0 + 1] * zr.y - a[r0 + 1] * zi.y);
+  }
+  static void agpr_reserve() {}
+  template <int I> static f32 agpr_get() { return g_agpr[I]; }
+  template <int I> static void agpr_set(const f32& x) { g_agpr[I] = x; }
+  static void pin(W4&) {}
+  static void sched_fence() {}
+  template <bool CONJ>
+  static void cmul2(A16& re, A16& im, int r0, const f32& tr0, const f32& tr1, const f32& ti0, const f32& ti1) {
+    const f32* tr[2] = {&tr0, &tr1}; const f32* ti[2] = {&ti0, &ti1};
+    for (int q = 0; q < 2; q++) {
+      f32 a = re[r0 + q], b = im[r0 + q];
+      if (!CONJ) { re[r0 + q] = a * *tr[q] - b * *ti[q]; im[r0 + q] = a * *ti[q] + b * *tr[q]; }
+      else { re[r0 + q] = a * *tr[q] + b * *ti[q]; im[r0 + q] = b * *tr[q] - a * *ti[q]; }
     }
   }
   static A16 a16_scale(const A16& a, float s) { A16 r; for (int i = 0; i < 16; i++) r[i] = a[i] * f32(s); return r; }
@@ -116,6 +142,9 @@ struct SimB {
       memcpy(&r.z.v[i], L() + off.v[i] + 8, 4); memcpy(&r.w.v[i], L() + off.v[i] + 12, 4);
     }
     return r;
+  }
+  static void lds_w16(const i32& off, const u32& v) {
+    for (int i = 0; i < 64; i++) { chk(off.v[i], 2); uint16_t h = (uint16_t)v.v[i]; memcpy(L() + off.v[i], &h, 2); }
   }
   static u32 lds_r32(const i32& off) {
     u32 r;
@@ -236,6 +265,8 @@ struct SimB {
   template <int DT> static f32 unpack_hi(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)(a.v[i] >> 16)); return r; }
 };
 bool SimB::HAS_TR = true;
+// mirrors DevBO: the backward kernels use the per-tile outer stages
+struct SimBO : SimB { static constexpr bool LEAN_OUTER = true; };
 static bool g_force_slow = false;
 
 // Run `fn(wg_index)` for one workgroup of nwaves wavefronts with lds_bytes of LDS.
@@ -290,14 +321,14 @@ template <class GEO, int DT> struct DkfRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimBO, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c); });
   }
 };
 template <class GEO, int DT> struct BwdRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c); });
   }
 };
 template <class GEO, int DT> struct DkRun {

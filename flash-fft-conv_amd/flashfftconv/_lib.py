@@ -6,7 +6,7 @@ csrc/flashfftconv/monarch_cuda/monarch_fwd.h:196-528)."""
 import ctypes, os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libflashfftconv_hip.so")
+LIB_PATH = os.environ.get("FFC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libflashfftconv_hip.so")   # FFC_LIB: tuning builds
 _lib = None
 
 c_vp, c_i64, c_int = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
