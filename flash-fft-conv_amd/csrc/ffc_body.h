@@ -239,8 +239,12 @@ struct Body {
   struct RowIO {
     const uint16_t* src[2]; const uint16_t* gate[2]; uint16_t* dst[2]; bool valid[2];
   };
+  // fast path: an unconditional 16-byte load from a clamped (always valid) position; positions beyond L and
+  // missing batch rows are zeroed when the registers are written to E (rows_store).  No branch, no
+  // zero-initialised destination: consecutive loads never wait for each other, and the loads of the next pair
+  // can stay in flight across phase C.
   static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, bool fast, bool rowok) {
-    if (fast) return B::g_r128p(base, n >> 3, (n < L) && rowok);
+    if (fast) return B::g_r128(base, B::imin(n, L - 8) >> 3);
     u32 w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -311,6 +315,11 @@ struct Body {
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
         U4 v = X.v[i][pl];
+        if (fast && GEO::OUTER) {        // masks of the unconditional fast-path loads
+          pred ok = ((row * GEO::Mi + m) < a.L) && ((2 * pq + pl) < a.B);
+          v.x = B::sel(ok, v.x, B::uconst(0)); v.y = B::sel(ok, v.y, B::uconst(0));
+          v.z = B::sel(ok, v.z, B::uconst(0)); v.w = B::sel(ok, v.w, B::uconst(0));
+        }
         if (a.pregate) {
           U4 g;
           if constexpr (GEO::OUTER) {
@@ -883,7 +892,12 @@ struct Body {
     constexpr int NC = HALF ? NCH / 2 : NCH;
     // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
     // arrive during the last tile / phase C / the stores and no earlier in-order vmcnt wait is delayed.
-    constexpr bool PREFETCH = false;   // measured: +5K cycles in phase B for -2.7K in rows_in (profiles/r01_phase_cycles.txt)
+    // The next pair's rows are requested right before phase C (no other global access until the stores of
+    // rows_out) and land in E at the top of the next iteration: their HBM latency hides behind phase C and
+    // the stores.  Requesting them any earlier (before phase B) costs more than it gains: the k_f loads of
+    // phase B retire in order behind them and the tile loop has no registers to spare
+    // (profiles/r01_phase_cycles.txt).
+    constexpr bool PREFETCH = HALF;    // full-length rows: 64 row registers on top of phase C would spill
     const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
     RowRegsT<NC> X;
     if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
@@ -927,6 +941,7 @@ struct Body {
       FFC_TICK(3)
       B::barrier();
       FFC_TICK(4)
+      if (PREFETCH && it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
       if (act) {
         outer_stage<false, HALF>(a.L, un);
         B::lds_fence();

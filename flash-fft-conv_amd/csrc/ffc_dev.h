@@ -128,6 +128,7 @@ struct DevB {
   // hide a value from LICM/CSE so per-phase address math is recomputed instead of kept live
   static FFC_FN i32 opaque(i32 x) { asm volatile("" : "+v"(x)); return x; }
   static FFC_FN u32 sel(pred p, u32 a, u32 b) { return p ? a : b; }
+  static FFC_FN i32 imin(i32 a, int b) { return a < b ? a : b; }
   static FFC_FN u32 g_r16(const void* base, i32 e, pred p) {
     uint16_t v = 0;
     if (p) v = ((const uint16_t*)base)[e];

@@ -182,6 +182,7 @@ struct SimB {
   static f32 sin_rev(const f32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)sin(6.283185307179586 * (double)a.v[i]); return r; }
   static i32 opaque(const i32& x) { return x; }
   static u32 uconst(uint32_t c) { return u32(c); }
+  static i32 imin(const i32& a, int b) { i32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
   static u32 sel(const pred& p, const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] ? a.v[i] : b.v[i]; return r; }
   static u32 g_r16(const void* base, const i32& e, const pred& p) {
     u32 r;
