@@ -33,9 +33,9 @@ def flops_fft_equiv(N):
     return 2 * 5 * N * lg + 6 * N, 3 * 5 * N * lg + 14 * N
 
 
-def time_kernel(fn, iters=10):
+def time_kernel(fn, iters=20):
     """HIP-event timing on torch's current stream (the stream the library launches on)."""
-    for _ in range(3):
+    for _ in range(20):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -135,6 +135,27 @@ struct Body {
       tr[4 + i] = tr[3 + i] * c1 - ti[3 + i] * s1; ti[4 + i] = tr[3 + i] * s1 + ti[3 + i] * c1;
     }
   }
+  // Same chain with packed math: pairs of consecutive rows {0,1},{2,3},{8,9},{10,11}; t1 = t0 w, then the pairs
+  // are stepped by w^2 and w^8 (two elements per packed instruction).
+  using F2 = typename B::F2;
+  static FFC_FN void chain8p(i32 base, i32 step, float sign, float scale, F2 (&tr)[4], F2 (&ti)[4]) {
+    f32 c0, s0, c1, s1, c8, s8;
+    cis_rev(base, sign, &c0, &s0);
+    cis_rev(step, sign, &c1, &s1);
+    cis_rev(step * 8, sign, &c8, &s8);
+    c0 = c0 * scale; s0 = s0 * scale;
+    f32 c2 = c1 * c1 - s1 * s1, s2 = (c1 + c1) * s1;
+    tr[0] = B::f2(c0, c0 * c1 - s0 * s1);
+    ti[0] = B::f2(s0, c0 * s1 + s0 * c1);
+    B::cmulp(tr[0], ti[0], c2, s2, tr[1], ti[1]);
+    B::cmulp(tr[0], ti[0], c8, s8, tr[2], ti[2]);
+    B::cmulp(tr[1], ti[1], c8, s8, tr[3], ti[3]);
+  }
+  // apply a chain8p result to accumulator rows 8*half + {0..7}
+  static FFC_FN void apply8(A16& re, A16& im, int half, const F2 (&tr)[4], const F2 (&ti)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) B::template cmul2v<false>(re, im, 8 * half + 2 * i, tr[i], ti[i]);
+  }
   // dtype pair (x) dtype pair, rounded back to dtype (the reference multiplies gates in the
   // activation dtype: kernels_bf16/monarch_cuda_32_32_32_kernel_bf16.h:409-429, 613-634).
   static FFC_FN u32 mul2(u32 a, u32 g) {
@@ -478,11 +499,9 @@ struct Body {
           const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
           i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + t);
           i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
-          f32 tr[8], ti[8];
-          chain8(m * k0, m, -1.0f, s_fwd, tr, ti);
-#pragma unroll
-          for (int i = 0; i < 8; i += 2)
-            B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
+          F2 tr[4], ti[4];
+          chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
+          apply8(re, im, half, tr, ti);
         }
       }
 #pragma unroll
@@ -564,15 +583,9 @@ struct Body {
             const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
             i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + 2 * tp + th);
             i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
-            f32 tr[8], ti[8];
-            chain8(m * k0, m, -1.0f, s_fwd, tr, ti);
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-              const int r = 8 * half + i;
-              f32 x = re[r], y = im[r];
-              re[r] = x * tr[i] - y * ti[i];
-              im[r] = x * ti[i] + y * tr[i];
-            }
+            F2 tr[4], ti[4];
+            chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
+            apply8(re, im, half, tr, ti);
           }
         }
 #pragma unroll
@@ -746,11 +759,9 @@ struct Body {
         const int sV = (16 * half) / GEO::N3;
         i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
         i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
-        f32 tr[8], ti[8];
-        chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);     // conj(W^{m k1}) = cos + i sin
-#pragma unroll
-        for (int i = 0; i < 8; i += 2)
-          B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
+        F2 tr[4], ti[4];
+        chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);     // conj(W^{m k1}) = cos + i sin
+        apply8(re, im, half, tr, ti);
       }
     }
     // write back in place: lane <-> (sU,n2), regs <-> (sV,n3); r&3 = 4 consecutive n3
@@ -821,11 +832,9 @@ struct Body {
       const int sV = (16 * half) / GEO::N3;
       i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
       i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
-      f32 tr[8], ti[8];
-      chain8(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
-#pragma unroll
-      for (int i = 0; i < 8; i += 2)
-        B::template cmul2<false>(re, im, 8 * half + i, tr[i], tr[i + 1], ti[i], ti[i + 1]);
+      F2 tr[4], ti[4];
+      chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
+      apply8(re, im, half, tr, ti);
     }
   }
   static FFC_FN void tile_store(int tau, const InnerRegs& R, const A16& re, const A16& im) {

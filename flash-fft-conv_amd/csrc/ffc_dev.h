@@ -49,6 +49,19 @@ struct DevB {
   static FFC_FN F2 f2(f32 a, f32 b) { F2 v = {a, b}; return v; }
   static FFC_FN f32 f2_lo(F2 v) { return v.x; }
   static FFC_FN f32 f2_hi(F2 v) { return v.y; }
+  // (yr, yi) = (xr, xi) * (wr + i wi) on a pair of complex values
+  static FFC_FN void cmulp(F2 xr, F2 xi, f32 wr, f32 wi, F2& yr, F2& yi) {
+    yr = xr * wr - xi * wi;
+    yi = xr * wi + xi * wr;
+  }
+  template <bool CONJ>
+  static FFC_FN void cmul2v(A16& re, A16& im, int r0, F2 tr, F2 ti) {
+    const F2 a = {re[r0], re[r0 + 1]}, b = {im[r0], im[r0 + 1]};
+    F2 x, y;
+    if (!CONJ) { x = a * tr - b * ti; y = a * ti + b * tr; }
+    else { x = a * tr + b * ti; y = b * tr - a * ti; }
+    re[r0] = x.x; re[r0 + 1] = x.y; im[r0] = y.x; im[r0 + 1] = y.y;
+  }
   // (wr, wi) += x[r0..r0+1] (x) conj z : packed fp32 math on register pairs
   static FFC_FN void cmac2_conj(F2& wr, F2& wi, const A16& a, const A16& b, int r0, F2 zr, F2 zi) {
     const F2 a2 = {a[r0], a[r0 + 1]}, b2 = {b[r0], b[r0 + 1]};

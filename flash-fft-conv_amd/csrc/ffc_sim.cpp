@@ -79,6 +79,14 @@ struct SimB {
   static F2 f2(const f32& a, const f32& b) { F2 v; v.x = a; v.y = b; return v; }
   static f32 f2_lo(const F2& v) { return v.x; }
   static f32 f2_hi(const F2& v) { return v.y; }
+  static void cmulp(const F2& xr, const F2& xi, const f32& wr, const f32& wi, F2& yr, F2& yi) {
+    F2 r, i;
+    r.x = xr.x * wr - xi.x * wi; r.y = xr.y * wr - xi.y * wi;
+    i.x = xr.x * wi + xi.x * wr; i.y = xr.y * wi + xi.y * wr;
+    yr = r; yi = i;
+  }
+  template <bool CONJ>
+  static void cmul2v(A16& re, A16& im, int r0, const F2& tr, const F2& ti) { cmul2<CONJ>(re, im, r0, tr.x, tr.y, ti.x, ti.y); }
   static void cmac2_conj(F2& wr, F2& wi, const A16& a, const A16& b, int r0, const F2& zr, const F2& zi) {
     wr.x = wr.x + (a[r0] * zr.x + b[r0] * zi.x);
     wr.y = wr.y + (a[r0 + 1] * zr.y + b[r0 + 1] * zi.y);
