@@ -64,8 +64,9 @@ struct Body {
     for (int q = 0; q < 6; q++) {
       U4 v = B::g_r128(p, lane + q * 64);
       m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
-      B::pin(m.w[q / 3][q % 3]);
     }
+#pragma unroll
+    for (int q = 0; q < 6; q++) B::pin(m.w[q / 3][q % 3]);
   }
   static FFC_FN void load_ct16(CT16& c, const uint8_t* p, i32 lane) {
 #pragma unroll
@@ -209,8 +210,10 @@ struct Body {
     for (int q = 0; q < 6; q++) {
       U4 v = B::lds_r128(lane * 16 + (off + q * 1024));
       m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
-      B::pin(m.w[q / 3][q % 3]);
     }
+    // after all six loads are in flight: the pin consumes its operand, i.e. waits for it
+#pragma unroll
+    for (int q = 0; q < 6; q++) B::pin(m.w[q / 3][q % 3]);
   }
   static FFC_FN void lds_ct16(CT16& c, int off) {
     const i32 lane = B::lane();
@@ -361,10 +364,11 @@ struct Body {
       }
     }
   }
+  template <int NC = NCH>
   static FFC_FN void rows_in(const ConvArgs& a, int h, int pq, Unit un) {
-    RowRegs X;
-    rows_load(a, h, pq, un, X);
-    rows_store(a, h, pq, un, X);
+    RowRegsT<NC> X;
+    rows_load<NC>(a, h, pq, un, X);
+    rows_store<NC>(a, h, pq, un, X);
   }
   // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
   // 32 bits in 16-byte units (launcher checks the tensor size).

@@ -455,7 +455,7 @@ struct Modes : Body<B, GEO, DT> {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
         if (act) {
-          BD::rows_in(av, h, p, un);
+          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(av, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
@@ -471,7 +471,7 @@ struct Modes : Body<B, GEO, DT> {
         }
         B::barrier();
         if (act) {
-          BD::rows_in(ad, h, p, un);
+          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
@@ -563,12 +563,14 @@ struct Modes : Body<B, GEO, DT> {
       uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
       WAcc W;
       w_acc_zero(W);
+      // (the forward kernel's early row request does not fit here: no phase has 32 registers to spare on the
+      // 128-VGPR budget, the allocator would overflow into the accumulation registers)
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
         if (act) {
-          BD::rows_in(av, h, p, un);
+          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(av, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
@@ -584,7 +586,7 @@ struct Modes : Body<B, GEO, DT> {
         }
         B::barrier();
         if (act) {
-          BD::rows_in(ad, h, p, un);
+          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
