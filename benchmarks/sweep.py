@@ -68,10 +68,15 @@ def conv1d_row():
         t_f = ev_time(lambda: m(x), 10)
     y = m(x)
     dout = torch.randn_like(y)
-    t_b = ev_time(lambda: y.backward(dout, retain_graph=True), 5)
+    def bwd():
+        x.grad = None
+        for prm in m.parameters():
+            prm.grad = None
+        y.backward(dout, retain_graph=True)
+    t_b = ev_time(bwd, 5)
     byts = B * L * D * 2 * 2 + K * D * 2
     print(json.dumps({"row": "cfg5 conv1d k=3 B=64 H=2048 L=8192 bf16 BHL", "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
-                      "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9)}), flush=True)
+                      "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9), "bwd_GBs": round(1.5 * byts / (t_b * 1e-3) / 1e9)}), flush=True)
 
 
 if __name__ == "__main__":

@@ -166,6 +166,79 @@ __global__ void bhl_wgrad_kernel(const typename El<TI>::S* __restrict__ dout, co
   }
 }
 
+// Fused BHL backward for "same" padding (Lout == L, P == (K-1)/2), K a compile-time constant: one pass over
+// dout and u (16-byte loads) produces du (16-byte stores) and the row's dw / dbias partial sums.
+// Replaces two passes (input gradient, then a scalar-load weight-gradient kernel): 3 tensors of traffic
+// instead of 4, and no 2-byte loads.
+template <int TI, int TW, int K>
+__global__ __launch_bounds__(256) void bhl_bwd_kernel(const typename El<TI>::S* __restrict__ dout,
+                                                      const typename El<TI>::S* __restrict__ u,
+                                                      const typename El<TW>::S* __restrict__ w, typename El<TI>::S* __restrict__ du,
+                                                      float* __restrict__ dw, float* __restrict__ dbias, int D, int L) {
+  constexpr int P = (K - 1) / 2;
+  static_assert(K - 1 <= V, "neighbour vectors cover K-1 <= V taps");
+  const int row = blockIdx.x;   // b*D + d
+  const int d = row % D;
+  float wk[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) wk[k] = El<TW>::ld(w[(size_t)d * K + k]);
+  const typename El<TI>::S* dr = dout + (size_t)row * L;
+  const typename El<TI>::S* ur = u + (size_t)row * L;
+  typename El<TI>::S* dur = du + (size_t)row * L;
+  float acc[K + 1];
+#pragma unroll
+  for (int k = 0; k <= K; k++) acc[k] = 0.f;
+  for (int l0 = threadIdx.x * V; l0 < L; l0 += blockDim.x * V) {
+    float g[3 * V], x[3 * V], t[V];
+    vload<TI>(dr + l0 - V, l0 - V >= 0, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) g[i] = t[i];
+    vload<TI>(dr + l0, true, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) g[V + i] = t[i];
+    vload<TI>(dr + l0 + V, l0 + 2 * V <= L, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) g[2 * V + i] = t[i];
+    vload<TI>(ur + l0 - V, l0 - V >= 0, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) x[i] = t[i];
+    vload<TI>(ur + l0, true, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) x[V + i] = t[i];
+    vload<TI>(ur + l0 + V, l0 + 2 * V <= L, t);
+#pragma unroll
+    for (int i = 0; i < V; i++) x[2 * V + i] = t[i];
+    float o[V];
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+      // du[l] = sum_k w[k] * dout[l + P - k];  dw[k] += dout[l] * u[l + k - P]
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        s += wk[k] * g[V + i + P - k];
+        acc[k] += g[V + i] * x[V + i + k - P];
+      }
+      o[i] = s;
+      acc[K] += g[V + i];
+    }
+    vstore<TI>(dur + l0, o);
+  }
+  __shared__ float red[K + 1][4];
+#pragma unroll
+  for (int k = 0; k <= K; k++) {
+    float v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x <= K) {
+    const int k = threadIdx.x;
+    float v = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+    if (k == K) atomicAdd(&dbias[d], v);
+    else atomicAdd(&dw[(size_t)d * K + k], v);
+  }
+}
+
 // ---------------------------------------------------------------- BLH forward / input-gradient
 // u (B,L,D), w (K,D).  One thread = V consecutive channels x TL consecutive positions.
 constexpr int TL = 4;
@@ -368,6 +441,22 @@ int ffc_conv1d_bwd(const void* dout, const void* u, const void* w, void* du, flo
   if (K < 1 || K > MAXK || (K % 2) != 1) return fail1d("kernel size must be odd and <= 15");
   int64_t Lout = L + 2 * (int64_t)P - K + 1;
   if (Lout <= 0) return fail1d("empty output");
+  // BHL, "same" padding, aligned rows: one fused pass
+  if (is_bhl && Lout == L && 2 * P == K - 1 && K <= 9 && L % V == 0 && B * D <= 2147483647LL &&
+      !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)du) & 15)) {
+    int rc = by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
+      constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
+      using SI = typename El<TI>::S;
+      using SW = typename El<TW>::S;
+      dim3 block(256), grid((unsigned)(B * D));
+#define FFC_L(KK) hipLaunchKernelGGL((bhl_bwd_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L)
+      switch (K) { case 1: FFC_L(1); break; case 3: FFC_L(3); break; case 5: FFC_L(5); break; case 7: FFC_L(7); break; default: FFC_L(9); break; }
+#undef FFC_L
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
+    });
+    return rc;
+  }
   // du[l] = sum_k w[k] * dout[l + P - k]: the same streaming kernel with the flipped kernel
   int rc = by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
     return launch_fwd<decltype(ti)::value, decltype(tw)::value>(dout, w, nullptr, du, B, D, Lout, L, K, P, is_bhl != 0, true, (hipStream_t)stream);
