@@ -11,7 +11,7 @@ SIM_SO = os.path.join(LIB, "libffcsim.so")
 #   addressed by hand in the backward kernels (dk_f partial sums) and must never be picked by the allocator.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "--amdgpu-mfma-vgpr-form", "-fPIC"]
 AGPR_CHECKED = ["ffc_k_dkf.hip"]     # translation units whose device code is scanned by check_agpr()
-HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_plan.cpp"]
+HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_conv1d_t0.hip", "ffc_conv1d_t1.hip", "ffc_conv1d_t2.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
 
@@ -89,7 +89,7 @@ def build_hip(force=False, verbose=False):
 
     # the checked translation units are compiled twice (object + device assembly for check_agpr), side by side
     jobs = [(f, False) for f in HIP_SRCS] + [(f, True) for f in AGPR_CHECKED]
-    jobs.sort(key=lambda j: j[0] not in AGPR_CHECKED)          # longest first
+    jobs.sort(key=lambda j: not (j[0] in AGPR_CHECKED or j[0].startswith('ffc_conv1d_t')))          # longest first
     with ThreadPoolExecutor(max_workers=min(10, os.cpu_count() or 4)) as ex:
         res = [r for r, j in zip(ex.map(compile_one, jobs), jobs) if not j[1]]
     objs = [o for o, _ in res]
@@ -102,11 +102,19 @@ def build_sim(force=False):
     os.makedirs(LIB, exist_ok=True)
     srcs = [os.path.join(CSRC, f) for f in SIM_SRCS]
     if force or _stale(SIM_SO, srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", SIM_SO] + srcs)
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", SIM_SO] + srcs)
     return SIM_SO
+
+
+def build_all(force=False, verbose=False):
+    """HIP library and the CPU simulator side by side (the simulator is one large g++ translation unit)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        sim = ex.submit(build_sim, force)
+        hip = build_hip(force, verbose)
+        return hip, sim.result()
 
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
-    print(build_hip(force, verbose=True))
-    print(build_sim(force))
+    print(build_all(force, verbose=True))

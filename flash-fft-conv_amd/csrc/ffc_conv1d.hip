@@ -1,470 +1,36 @@
-// Short depthwise conv1d (K odd, usually 3/5/7), HBM-bound streaming kernels for gfx950.
-//   y[b,d,l] = bias[d] + sum_k w[d,k] * u[b,d,l+k-P],  L_out = L + 2P - K + 1
-// Replaces reference csrc/flashfftconv/conv1d/{conv1d_bhl,conv1d_blh,conv1d_bwd_cuda_bhl,
-// conv1d_bwd_cuda_blh}.cu.  Differences by design: fp32 accumulation (the reference accumulates in
-// the input dtype, conv1d_bhl.cu:13-43), 16-byte vector accesses along the contiguous axis, and a
-// backward that reduces dw/dbias in registers + one fp32 atomic per block instead of materialising
-// the (B,D,K,L) im2col tensor (conv1d_bwd_cuda_bhl.cu:10-105).
-#include <hip/hip_runtime.h>
+// C-ABI entry points of the short depthwise conv1d: dispatch on the input dtype to the three translation
+// units that hold the kernels (ffc_conv1d_t{0,1,2}.hip <- ffc_conv1d_impl.h).
 #include <stdint.h>
-
-#include <algorithm>
-#include <string>
-#include <type_traits>
 
 #include "../../include/flashfftconv_hip.h"
 
-namespace {
-
-enum { T_BF16 = 0, T_F16 = 1, T_F32 = 2 };
-
-template <int T> struct El;
-template <> struct El<T_BF16> {
-  using S = uint16_t;
-  static __device__ __forceinline__ float ld(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
-  static __device__ __forceinline__ uint16_t st(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
-};
-template <> struct El<T_F16> {
-  using S = uint16_t;
-  static __device__ __forceinline__ float ld(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
-  static __device__ __forceinline__ uint16_t st(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
-};
-template <> struct El<T_F32> {
-  using S = float;
-  static __device__ __forceinline__ float ld(float v) { return v; }
-  static __device__ __forceinline__ float st(float f) { return f; }
-};
-
-constexpr int MAXK = 15;
-constexpr int V = 8;   // elements per thread along the contiguous axis
-
-// aligned vector load of V elements -> float; `ok` false -> zeros
-template <int T>
-__device__ __forceinline__ void vload(const typename El<T>::S* p, bool ok, float (&v)[V]) {
-  if (!ok) {
-#pragma unroll
-    for (int i = 0; i < V; i++) v[i] = 0.f;
-    return;
-  }
-  if constexpr (T == T_F32) {
-    float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    uint4 a = *(const uint4*)p;
-    uint32_t w[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) { v[2 * i] = El<T>::ld((uint16_t)(w[i] & 0xffff)); v[2 * i + 1] = El<T>::ld((uint16_t)(w[i] >> 16)); }
-  }
-}
-template <int T>
-__device__ __forceinline__ void vstore(typename El<T>::S* p, const float (&v)[V]) {
-  if constexpr (T == T_F32) {
-    ((float4*)p)[0] = make_float4(v[0], v[1], v[2], v[3]);
-    ((float4*)p)[1] = make_float4(v[4], v[5], v[6], v[7]);
-  } else {
-    uint32_t w[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = (uint32_t)El<T>::st(v[2 * i]) | ((uint32_t)El<T>::st(v[2 * i + 1]) << 16);
-    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
-  }
-}
-
-// ---------------------------------------------------------------- BHL forward / input-gradient
-// One thread = V consecutive outputs of one (b,d) row.  FLIP: correlate with the flipped kernel
-// (du[l] = sum_k w[k] * dout[l + P - k]).  Fast path needs Lin % V == 0, Lout % V == 0.
-template <int TI, int TW, bool FLIP, bool FAST>
-__global__ void bhl_kernel(const typename El<TI>::S* __restrict__ u, const typename El<TW>::S* __restrict__ w,
-                           const typename El<TW>::S* __restrict__ bias, typename El<TI>::S* __restrict__ y, int D, int Lin,
-                           int Lout, int K, int P) {
-  const int nch = (Lout + V * (int)blockDim.x - 1) / (V * (int)blockDim.x);
-  const int row = blockIdx.x / nch;   // b*D + d
-  const int d = row % D;
-  const int l0 = ((blockIdx.x % nch) * blockDim.x + threadIdx.x) * V;
-  if (l0 >= Lout) return;
-  float wk[MAXK];
-#pragma unroll
-  for (int k = 0; k < MAXK; k++) wk[k] = k < K ? El<TW>::ld(w[(size_t)d * K + (FLIP ? K - 1 - k : k)]) : 0.f;
-  const float b0 = bias ? El<TW>::ld(bias[d]) : 0.f;
-  const typename El<TI>::S* ur = u + (size_t)row * Lin;
-  float acc[V];
-#pragma unroll
-  for (int i = 0; i < V; i++) acc[i] = b0;
-  const int shift = FLIP ? (K - 1 - P) : P;   // input index = l + k - shift
-  if (FAST) {
-    float x[3 * V];
-    float t[V];
-    vload<TI>(ur + l0 - V, l0 - V >= 0, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[i] = t[i];
-    vload<TI>(ur + l0, l0 + V <= Lin, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[V + i] = t[i];
-    vload<TI>(ur + l0 + V, l0 + 2 * V <= Lin, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[2 * V + i] = t[i];
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) {
-      if (k < K) {
-#pragma unroll
-        for (int i = 0; i < V; i++) {
-          int idx = V + i + k - shift;   // within [V - shift, 2V + K - 2 - shift] subset of [0, 3V)
-          acc[i] += wk[k] * x[idx];
-        }
-      }
-    }
-    vstore<TI>(y + (size_t)row * Lout + l0, acc);
-  } else {
-    for (int i = 0; i < V; i++) {
-      int l = l0 + i;
-      if (l >= Lout) break;
-      float a = b0;
-      for (int k = 0; k < K; k++) {
-        int j = l + k - shift;
-        if (j >= 0 && j < Lin) a += wk[k] * El<TI>::ld(ur[j]);
-      }
-      y[(size_t)row * Lout + l] = El<TI>::st(a);
-    }
-  }
-}
-
-// dw[d,k] += sum_{l} dout[b,d,l] * u[b,d,l+k-P];  dbias[d] += sum_l dout[b,d,l]   (one (b,d) row chunk per block)
-template <int TI>
-__global__ void bhl_wgrad_kernel(const typename El<TI>::S* __restrict__ dout, const typename El<TI>::S* __restrict__ u,
-                                 float* __restrict__ dw, float* __restrict__ dbias, int D, int L, int Lout, int K, int P, int nch) {
-  const int row = blockIdx.x / nch;
-  const int d = row % D;
-  const typename El<TI>::S* dr = dout + (size_t)row * Lout;
-  const typename El<TI>::S* ur = u + (size_t)row * L;
-  float acc[MAXK + 1];
-#pragma unroll
-  for (int k = 0; k <= MAXK; k++) acc[k] = 0.f;
-  for (int l = (blockIdx.x % nch) * blockDim.x + threadIdx.x; l < Lout; l += nch * blockDim.x) {
-    float g = El<TI>::ld(dr[l]);
-    acc[MAXK] += g;
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) {
-      if (k < K) {
-        int j = l + k - P;
-        if (j >= 0 && j < L) acc[k] += g * El<TI>::ld(ur[j]);
-      }
-    }
-  }
-  __shared__ float red[MAXK + 1][4];
-#pragma unroll
-  for (int k = 0; k <= MAXK; k++) {
-    float v = acc[k];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x <= MAXK) {
-    int k = threadIdx.x;
-    float v = 0.f;
-    for (int wv = 0; wv < (int)(blockDim.x >> 6); wv++) v += red[k][wv];
-    if (k == MAXK) atomicAdd(&dbias[d], v);
-    else if (k < K) atomicAdd(&dw[(size_t)d * K + k], v);
-  }
-}
-
-// Fused BHL backward for "same" padding (Lout == L, P == (K-1)/2), K a compile-time constant: one pass over
-// dout and u (16-byte loads) produces du (16-byte stores) and the row's dw / dbias partial sums.
-// Replaces two passes (input gradient, then a scalar-load weight-gradient kernel): 3 tensors of traffic
-// instead of 4, and no 2-byte loads.
-template <int TI, int TW, int K>
-__global__ __launch_bounds__(256) void bhl_bwd_kernel(const typename El<TI>::S* __restrict__ dout,
-                                                      const typename El<TI>::S* __restrict__ u,
-                                                      const typename El<TW>::S* __restrict__ w, typename El<TI>::S* __restrict__ du,
-                                                      float* __restrict__ dw, float* __restrict__ dbias, int D, int L) {
-  constexpr int P = (K - 1) / 2;
-  static_assert(K - 1 <= V, "neighbour vectors cover K-1 <= V taps");
-  const int row = blockIdx.x;   // b*D + d
-  const int d = row % D;
-  float wk[K];
-#pragma unroll
-  for (int k = 0; k < K; k++) wk[k] = El<TW>::ld(w[(size_t)d * K + k]);
-  const typename El<TI>::S* dr = dout + (size_t)row * L;
-  const typename El<TI>::S* ur = u + (size_t)row * L;
-  typename El<TI>::S* dur = du + (size_t)row * L;
-  float acc[K + 1];
-#pragma unroll
-  for (int k = 0; k <= K; k++) acc[k] = 0.f;
-  for (int l0 = threadIdx.x * V; l0 < L; l0 += blockDim.x * V) {
-    float g[3 * V], x[3 * V], t[V];
-    vload<TI>(dr + l0 - V, l0 - V >= 0, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) g[i] = t[i];
-    vload<TI>(dr + l0, true, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) g[V + i] = t[i];
-    vload<TI>(dr + l0 + V, l0 + 2 * V <= L, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) g[2 * V + i] = t[i];
-    vload<TI>(ur + l0 - V, l0 - V >= 0, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[i] = t[i];
-    vload<TI>(ur + l0, true, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[V + i] = t[i];
-    vload<TI>(ur + l0 + V, l0 + 2 * V <= L, t);
-#pragma unroll
-    for (int i = 0; i < V; i++) x[2 * V + i] = t[i];
-    float o[V];
-#pragma unroll
-    for (int i = 0; i < V; i++) {
-      // du[l] = sum_k w[k] * dout[l + P - k];  dw[k] += dout[l] * u[l + k - P]
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < K; k++) {
-        s += wk[k] * g[V + i + P - k];
-        acc[k] += g[V + i] * x[V + i + k - P];
-      }
-      o[i] = s;
-      acc[K] += g[V + i];
-    }
-    vstore<TI>(dur + l0, o);
-  }
-  __shared__ float red[K + 1][4];
-#pragma unroll
-  for (int k = 0; k <= K; k++) {
-    float v = acc[k];
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x <= K) {
-    const int k = threadIdx.x;
-    float v = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-    if (k == K) atomicAdd(&dbias[d], v);
-    else atomicAdd(&dw[(size_t)d * K + k], v);
-  }
-}
-
-// ---------------------------------------------------------------- BLH forward / input-gradient
-// u (B,L,D), w (K,D).  One thread = V consecutive channels x TL consecutive positions.
-constexpr int TL = 4;
-template <int TI, int TW, bool FLIP, bool FAST>
-__global__ void blh_kernel(const typename El<TI>::S* __restrict__ u, const typename El<TW>::S* __restrict__ w,
-                           const typename El<TW>::S* __restrict__ bias, typename El<TI>::S* __restrict__ y, int D, int Lin,
-                           int Lout, int K, int P) {
-  const int d0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-  if (d0 >= D) return;
-  const int b = blockIdx.z;
-  const int l0 = blockIdx.y * TL;
-  const int shift = FLIP ? (K - 1 - P) : P;
-  float acc[TL][V];
-  float bv[V];
-  if (bias) {
-    if (FAST) vload<TW>(bias + d0, true, bv);
-    else
-      for (int i = 0; i < V; i++) bv[i] = d0 + i < D ? El<TW>::ld(bias[d0 + i]) : 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < V; i++) bv[i] = 0.f;
-  }
-#pragma unroll
-  for (int t = 0; t < TL; t++)
-#pragma unroll
-    for (int i = 0; i < V; i++) acc[t][i] = bv[i];
-  const typename El<TI>::S* ub = u + (size_t)b * Lin * D;
-  for (int r = 0; r < TL + K - 1; r++) {   // input row j feeds outputs l = j - k + shift
-    int j = l0 - shift + r;
-    if (j < 0 || j >= Lin) continue;
-    float x[V];
-    if (FAST) vload<TI>(ub + (size_t)j * D + d0, true, x);
-    else
-      for (int i = 0; i < V; i++) x[i] = d0 + i < D ? El<TI>::ld(ub[(size_t)j * D + d0 + i]) : 0.f;
-#pragma unroll
-    for (int t = 0; t < TL; t++) {
-      int k = r - t;   // l = l0 + t = j - k + shift
-      if (k < 0 || k >= K) continue;
-      int kk = FLIP ? K - 1 - k : k;
-      float wv[V];
-      if (FAST) vload<TW>(w + (size_t)kk * D + d0, true, wv);
-      else
-        for (int i = 0; i < V; i++) wv[i] = d0 + i < D ? El<TW>::ld(w[(size_t)kk * D + d0 + i]) : 0.f;
-#pragma unroll
-      for (int i = 0; i < V; i++) acc[t][i] += wv[i] * x[i];
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < TL; t++) {
-    int l = l0 + t;
-    if (l >= Lout) break;
-    typename El<TI>::S* yp = y + ((size_t)b * Lout + l) * D + d0;
-    if (FAST) vstore<TI>(yp, acc[t]);
-    else
-      for (int i = 0; i < V; i++)
-        if (d0 + i < D) yp[i] = El<TI>::st(acc[t][i]);
-  }
-}
-
-// dw[k,d], dbias[d] for BLH: thread = V channels, block loops over a slab of (b,l) rows.
-template <int TI, bool FAST>
-__global__ void blh_wgrad_kernel(const typename El<TI>::S* __restrict__ dout, const typename El<TI>::S* __restrict__ u,
-                                 float* __restrict__ dw, float* __restrict__ dbias, int B, int D, int L, int Lout, int K, int P,
-                                 int rows_per_block) {
-  const int d0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-  if (d0 >= D) return;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-  const int64_t total = (int64_t)B * Lout;
-  float acc[MAXK + 1][V];
-#pragma unroll
-  for (int k = 0; k <= MAXK; k++)
-#pragma unroll
-    for (int i = 0; i < V; i++) acc[k][i] = 0.f;
-  for (int64_t r = r0; r < r0 + rows_per_block && r < total; r++) {
-    int b = (int)(r / Lout), l = (int)(r % Lout);
-    float g[V];
-    if (FAST) vload<TI>(dout + (size_t)r * D + d0, true, g);
-    else
-      for (int i = 0; i < V; i++) g[i] = d0 + i < D ? El<TI>::ld(dout[(size_t)r * D + d0 + i]) : 0.f;
-#pragma unroll
-    for (int i = 0; i < V; i++) acc[MAXK][i] += g[i];
-#pragma unroll
-    for (int k = 0; k < MAXK; k++) {
-      if (k < K) {
-        int j = l + k - P;
-        if (j >= 0 && j < L) {
-          float x[V];
-          const typename El<TI>::S* up = u + ((size_t)b * L + j) * D + d0;
-          if (FAST) vload<TI>(up, true, x);
-          else
-            for (int i = 0; i < V; i++) x[i] = d0 + i < D ? El<TI>::ld(up[i]) : 0.f;
-#pragma unroll
-          for (int i = 0; i < V; i++) acc[k][i] += g[i] * x[i];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < V; i++) {
-    if (d0 + i < D) {
-      atomicAdd(&dbias[d0 + i], acc[MAXK][i]);
-#pragma unroll
-      for (int k = 0; k < MAXK; k++)
-        if (k < K) atomicAdd(&dw[(size_t)k * D + d0 + i], acc[k][i]);
-    }
-  }
-}
-
-thread_local std::string g_err1d;
-int fail1d(const char* m);
-
-template <int TI, int TW>
-int launch_fwd(const void* u, const void* w, const void* bias, void* y, int64_t B, int64_t D, int64_t Lin, int64_t Lout, int K,
-               int P, bool bhl, bool flip, hipStream_t st) {
-  using SI = typename El<TI>::S;
-  using SW = typename El<TW>::S;
-  const int esz = sizeof(SI);
-  if (bhl) {
-    bool fast = (Lin % V == 0) && (Lout % V == 0) && (K - 1 <= V) && !(((uintptr_t)u | (uintptr_t)y) & 15) && esz * V % 16 == 0;
-    int64_t nblk = ((Lout + V * 256 - 1) / (V * 256)) * B * D;
-    if (nblk > 2147483647LL) return fail1d("grid too large");
-    dim3 block(256), grid((unsigned)nblk);
-#define FFC_L(FL, FA) hipLaunchKernelGGL((bhl_kernel<TI, TW, FL, FA>), grid, block, 0, st, (const SI*)u, (const SW*)w, (const SW*)bias, (SI*)y, (int)D, (int)Lin, (int)Lout, K, P)
-    if (flip) { if (fast) FFC_L(true, true); else FFC_L(true, false); }
-    else { if (fast) FFC_L(false, true); else FFC_L(false, false); }
-#undef FFC_L
-  } else {
-    bool fast = (D % V == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias) & 15);
-    int tx = 64;
-    dim3 block(tx), grid((unsigned)((D + V * tx - 1) / (V * tx)), (unsigned)((Lout + TL - 1) / TL), (unsigned)B);
-#define FFC_L(FL, FA) hipLaunchKernelGGL((blh_kernel<TI, TW, FL, FA>), grid, block, 0, st, (const SI*)u, (const SW*)w, (const SW*)bias, (SI*)y, (int)D, (int)Lin, (int)Lout, K, P)
-    if (flip) { if (fast) FFC_L(true, true); else FFC_L(true, false); }
-    else { if (fast) FFC_L(false, true); else FFC_L(false, false); }
-#undef FFC_L
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail1d(hipGetErrorString(e));
-  return 0;
-}
-
-template <int TI>
-int launch_wgrad(const void* dout, const void* u, float* dw, float* dbias, int64_t B, int64_t D, int64_t L, int64_t Lout, int K,
-                 int P, bool bhl, hipStream_t st) {
-  using SI = typename El<TI>::S;
-  if (bhl) {
-    int nch = (int)std::min<int64_t>((Lout + 255) / 256, 8);
-    int64_t nblk = (int64_t)nch * B * D;
-    if (nblk > 2147483647LL) return fail1d("grid too large");
-    dim3 block(256), grid((unsigned)nblk);
-    hipLaunchKernelGGL((bhl_wgrad_kernel<TI>), grid, block, 0, st, (const SI*)dout, (const SI*)u, dw, dbias, (int)D, (int)L,
-                       (int)Lout, K, P, nch);
-  } else {
-    bool fast = (D % V == 0) && !(((uintptr_t)u | (uintptr_t)dout) & 15);
-    int tx = 64;
-    int64_t total = B * Lout;
-    int rpb = (int)std::max<int64_t>(64, (total + 1023) / 1024);
-    dim3 block(tx), grid((unsigned)((D + V * tx - 1) / (V * tx)), (unsigned)((total + rpb - 1) / rpb));
-    if (fast)
-      hipLaunchKernelGGL((blh_wgrad_kernel<TI, true>), grid, block, 0, st, (const SI*)dout, (const SI*)u, dw, dbias, (int)B, (int)D,
-                         (int)L, (int)Lout, K, P, rpb);
-    else
-      hipLaunchKernelGGL((blh_wgrad_kernel<TI, false>), grid, block, 0, st, (const SI*)dout, (const SI*)u, dw, dbias, (int)B,
-                         (int)D, (int)L, (int)Lout, K, P, rpb);
-  }
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail1d(hipGetErrorString(e));
-  return 0;
-}
-
-template <class F>
-int by_dtypes(int ti, int tw, F f) {
-#define FFC_C(a, b) if (ti == a && tw == b) return f(std::integral_constant<int, a>(), std::integral_constant<int, b>());
-  FFC_C(0, 0) FFC_C(0, 1) FFC_C(0, 2) FFC_C(1, 0) FFC_C(1, 1) FFC_C(1, 2) FFC_C(2, 0) FFC_C(2, 1) FFC_C(2, 2)
-#undef FFC_C
-  return fail1d("unsupported dtype combination");
-}
-
-}  // namespace
-
-// error plumbing shared with ffc_hip.hip
 extern "C" void ffc_set_error_(const char* m);
-namespace { int fail1d(const char* m) { ffc_set_error_(m); return 1; } }
-
 extern "C" {
+#define FFC_DECL(n)                                                                                                        \
+  int ffc_c1d_fwd_##n(const void*, const void*, const void*, void*, int, int, int64_t, int64_t, int64_t, int, int, int, void*); \
+  int ffc_c1d_bwd_##n(const void*, const void*, const void*, void*, float*, float*, int, int, int64_t, int64_t, int64_t, int, int, int, void*);
+FFC_DECL(0) FFC_DECL(1) FFC_DECL(2)
+#undef FFC_DECL
 
 int ffc_conv1d_fwd(const void* u, const void* w, const void* bias, void* y, int in_dtype, int w_dtype, int64_t B, int64_t D,
                    int64_t L, int K, int P, int is_bhl, void* stream) {
-  if (!u || !w || !y) return fail1d("null arg");
-  if (K < 1 || K > MAXK || (K % 2) != 1) return fail1d("kernel size must be odd and <= 15");
-  int64_t Lout = L + 2 * (int64_t)P - K + 1;
-  if (Lout <= 0) return fail1d("empty output");
-  return by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
-    return launch_fwd<decltype(ti)::value, decltype(tw)::value>(u, w, bias, y, B, D, L, Lout, K, P, is_bhl != 0, false, (hipStream_t)stream);
-  });
+  switch (in_dtype) {
+    case 0: return ffc_c1d_fwd_0(u, w, bias, y, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
+    case 1: return ffc_c1d_fwd_1(u, w, bias, y, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
+    case 2: return ffc_c1d_fwd_2(u, w, bias, y, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
+  }
+  ffc_set_error_("unsupported dtype combination");
+  return 1;
 }
 
 int ffc_conv1d_bwd(const void* dout, const void* u, const void* w, void* du, float* dw, float* dbias, int in_dtype, int w_dtype,
                    int64_t B, int64_t D, int64_t L, int K, int P, int is_bhl, void* stream) {
-  if (!dout || !u || !w || !du || !dw || !dbias) return fail1d("null arg");
-  if (K < 1 || K > MAXK || (K % 2) != 1) return fail1d("kernel size must be odd and <= 15");
-  int64_t Lout = L + 2 * (int64_t)P - K + 1;
-  if (Lout <= 0) return fail1d("empty output");
-  // BHL, "same" padding, aligned rows: one fused pass
-  if (is_bhl && Lout == L && 2 * P == K - 1 && K <= 9 && L % V == 0 && B * D <= 2147483647LL &&
-      !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)du) & 15)) {
-    int rc = by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
-      constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
-      using SI = typename El<TI>::S;
-      using SW = typename El<TW>::S;
-      dim3 block(256), grid((unsigned)(B * D));
-#define FFC_L(KK) hipLaunchKernelGGL((bhl_bwd_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L)
-      switch (K) { case 1: FFC_L(1); break; case 3: FFC_L(3); break; case 5: FFC_L(5); break; case 7: FFC_L(7); break; default: FFC_L(9); break; }
-#undef FFC_L
-      hipError_t e = hipGetLastError();
-      return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
-    });
-    return rc;
+  switch (in_dtype) {
+    case 0: return ffc_c1d_bwd_0(dout, u, w, du, dw, dbias, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
+    case 1: return ffc_c1d_bwd_1(dout, u, w, du, dw, dbias, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
+    case 2: return ffc_c1d_bwd_2(dout, u, w, du, dw, dbias, in_dtype, w_dtype, B, D, L, K, P, is_bhl, stream);
   }
-  // du[l] = sum_k w[k] * dout[l + P - k]: the same streaming kernel with the flipped kernel
-  int rc = by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
-    return launch_fwd<decltype(ti)::value, decltype(tw)::value>(dout, w, nullptr, du, B, D, Lout, L, K, P, is_bhl != 0, true, (hipStream_t)stream);
-  });
-  if (rc) return rc;
-  return by_dtypes(in_dtype, 0, [&](auto ti, auto) {
-    return launch_wgrad<decltype(ti)::value>(dout, u, dw, dbias, B, D, L, Lout, K, P, is_bhl != 0, (hipStream_t)stream);
-  });
+  ffc_set_error_("unsupported dtype combination");
+  return 1;
 }
-
-}  // extern "C"
+}
