@@ -418,6 +418,71 @@ int launch_fwd(const void* u, const void* w, const void* bias, void* y, int64_t 
   return 0;
 }
 
+// Fused BLH backward for "same" padding, K in {3, 5}: a thread owns V channels and walks a slab of consecutive
+// positions of one batch with K-row sliding windows of dout and u in registers (slot = row mod K, static after
+// unrolling by K): every row of dout / u is loaded once (16 bytes per lane, 1 KiB per wave), du is stored as it
+// goes, dw / dbias sums leave through one fp32 atomic per value at the end of the slab.
+template <int TI, int TW, int K>
+__global__ __launch_bounds__(64) void blh_bwd_kernel(const typename El<TI>::S* __restrict__ dout, const typename El<TI>::S* __restrict__ u,
+                                                     const typename El<TW>::S* __restrict__ w, typename El<TI>::S* __restrict__ du,
+                                                     float* __restrict__ dw, float* __restrict__ dbias, int D, int L, int R) {
+  constexpr int P = (K - 1) / 2;
+  const int d0 = (blockIdx.x * 64 + threadIdx.x) * V;
+  if (d0 >= D) return;
+  const int slabs = (L + R - 1) / R;
+  const int b = blockIdx.y / slabs;
+  const int r0 = (blockIdx.y % slabs) * R;
+  const int r1 = min(r0 + R, L);
+  const size_t base = (size_t)b * L * D + d0;
+  float wk[K][V], g[K][V], x[K][V], acc[K + 1][V];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    vload<TW>(w + (size_t)k * D + d0, true, wk[k]);
+#pragma unroll
+    for (int i = 0; i < V; i++) { acc[k][i] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < V; i++) acc[K][i] = 0.f;
+  // rows r0-P .. r0+P-1 -> slots (j - r0 + P) mod K
+#pragma unroll
+  for (int t = 0; t < 2 * P; t++) {
+    const int j = r0 - P + t;
+    vload<TI>(dout + base + (size_t)j * D, j >= 0 && j < L, g[t % K]);
+    vload<TI>(u + base + (size_t)j * D, j >= 0 && j < L, x[t % K]);
+  }
+  for (int lb = r0; lb < r1; lb += K) {
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const int l = lb + s;
+      if (l < r1) {
+        const int jn = l + P;
+        vload<TI>(dout + base + (size_t)jn * D, jn < L, g[(s + K - 1) % K]);
+        vload<TI>(u + base + (size_t)jn * D, jn < L, x[(s + K - 1) % K]);
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+          float sum = 0.f;
+          const float gl = g[(s + P) % K][i];
+#pragma unroll
+          for (int k = 0; k < K; k++) {
+            sum += wk[k][i] * g[(s + 2 * P - k) % K][i];     // du[l] = sum_k w[k] dout[l + P - k]
+            acc[k][i] += gl * x[(s + k) % K][i];              // dw[k] += dout[l] u[l + k - P]
+          }
+          acc[K][i] += gl;
+          o[i] = sum;
+        }
+        vstore<TI>(du + base + (size_t)l * D, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; i++) {
+    atomicAdd(&dbias[d0 + i], acc[K][i]);
+#pragma unroll
+    for (int k = 0; k < K; k++) atomicAdd(&dw[(size_t)k * D + d0 + i], acc[k][i]);
+  }
+}
+
 template <int TI>
 int launch_wgrad(const void* dout, const void* u, float* dw, float* dbias, int64_t B, int64_t D, int64_t L, int64_t Lout, int K,
                  int P, bool bhl, hipStream_t st) {
@@ -513,6 +578,24 @@ int FFC_C1D_NAME(ffc_c1d_bwd_)(const void* dout, const void* u, const void* w, v
       return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
     });
     return rc;
+  }
+  // BLH, "same" padding, K in {3,5}, aligned channel vectors: one fused pass
+  if (!is_bhl && Lout == L && 2 * P == K - 1 && (K == 3 || K == 5) && D % V == 0 &&
+      !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)du | (uintptr_t)w) & 15)) {
+    return by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
+      constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
+      using SI = typename El<TI>::S;
+      using SW = typename El<TW>::S;
+      int R = (int)std::max<int64_t>(64, (B * L + 1023) / 1024);      // ~1024 slabs
+      R = (int)std::min<int64_t>(R, L);
+      const int64_t slabs = (L + R - 1) / R;
+      if (B * slabs > 65535) return fail1d("grid too large");
+      dim3 block(64), grid((unsigned)((D / V + 63) / 64), (unsigned)(B * slabs));
+      if (K == 3) hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 3>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
+      else hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 5>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
+      hipError_t e = hipGetLastError();
+      return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
+    });
   }
   // du[l] = sum_k w[k] * dout[l + P - k]: the same streaming kernel with the flipped kernel
   int rc = by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
