@@ -483,6 +483,50 @@ __global__ __launch_bounds__(64) void blh_bwd_kernel(const typename El<TI>::S* _
   }
 }
 
+// BLH forward for "same" padding, K in {3, 5, 7}: same sliding-window walk as blh_bwd_kernel, every input row is
+// loaded once (the tiled kernel above re-reads (TL+K-1)/TL rows per output row).
+template <int TI, int TW, int K>
+__global__ __launch_bounds__(64) void blh_same_kernel(const typename El<TI>::S* __restrict__ u, const typename El<TW>::S* __restrict__ w,
+                                                      const typename El<TW>::S* __restrict__ bias, typename El<TI>::S* __restrict__ y,
+                                                      int D, int L, int R) {
+  constexpr int P = (K - 1) / 2;
+  const int d0 = (blockIdx.x * 64 + threadIdx.x) * V;
+  if (d0 >= D) return;
+  const int slabs = (L + R - 1) / R;
+  const int b = blockIdx.y / slabs;
+  const int r0 = (blockIdx.y % slabs) * R;
+  const int r1 = min(r0 + R, L);
+  const size_t base = (size_t)b * L * D + d0;
+  float wk[K][V], x[K][V], bv[V];
+#pragma unroll
+  for (int k = 0; k < K; k++) vload<TW>(w + (size_t)k * D + d0, true, wk[k]);
+  vload<TW>(bias + d0, bias != nullptr, bv);
+#pragma unroll
+  for (int t = 0; t < 2 * P; t++) {
+    const int j = r0 - P + t;
+    vload<TI>(u + base + (size_t)j * D, j >= 0 && j < L, x[t % K]);
+  }
+  for (int lb = r0; lb < r1; lb += K) {
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const int l = lb + s;
+      if (l < r1) {
+        const int jn = l + P;
+        vload<TI>(u + base + (size_t)jn * D, jn < L, x[(s + K - 1) % K]);
+        float o[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+          float sum = bv[i];
+#pragma unroll
+          for (int k = 0; k < K; k++) sum += wk[k][i] * x[(s + k) % K][i];     // y[l] = sum_k w[k] u[l + k - P]
+          o[i] = sum;
+        }
+        vstore<TI>(y + base + (size_t)l * D, o);
+      }
+    }
+  }
+}
+
 template <int TI>
 int launch_wgrad(const void* dout, const void* u, float* dw, float* dbias, int64_t B, int64_t D, int64_t L, int64_t Lout, int K,
                  int P, bool bhl, hipStream_t st) {
@@ -547,6 +591,25 @@ int FFC_C1D_NAME(ffc_c1d_fwd_)(const void* u, const void* w, const void* bias, v
         dim3 block(256), grid((unsigned)(nch * B * D));
 #define FFC_L(KK) hipLaunchKernelGGL((bhl_same_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)u, (const SW*)w, (const SW*)bias, (SI*)y, (int)D, (int)L, nch)
         switch (K) { case 1: FFC_L(1); break; case 3: FFC_L(3); break; case 5: FFC_L(5); break; case 7: FFC_L(7); break; default: FFC_L(9); break; }
+#undef FFC_L
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
+      });
+  }
+  // (K = 3 stays on the tiled kernel: 1.5 row reads per output row, measured faster than the serial walk)
+  if (!is_bhl && Lout == L && 2 * P == K - 1 && (K == 5 || K == 7) && D % V == 0 &&
+      !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)w | (uintptr_t)bias) & 15)) {
+    int R = (int)std::max<int64_t>(32, (B * L + 2047) / 2048);      // ~2048 slabs
+    R = (int)std::min<int64_t>(R, L);
+    const int64_t slabs = (L + R - 1) / R;
+    if (B * slabs <= 65535)
+      return by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
+        constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
+        using SI = typename El<TI>::S;
+        using SW = typename El<TW>::S;
+        dim3 block(64), grid((unsigned)((D / V + 63) / 64), (unsigned)(B * slabs));
+#define FFC_L(KK) hipLaunchKernelGGL((blh_same_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)u, (const SW*)w, (const SW*)bias, (SI*)y, (int)D, (int)L, R)
+        if (K == 5) FFC_L(5); else FFC_L(7);
 #undef FFC_L
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
