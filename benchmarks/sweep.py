@@ -90,7 +90,5 @@ if __name__ == "__main__":
         for lg in range(10, 21):
             L = 1 << lg
             N = 2 * L
-            if N == 2048:
-                continue        # fft size 2048 not implemented yet
             Hrun = 768 if N <= 131072 else max(16, 768 * 131072 // N)
             conv_row(f"sweep L={L}", N, 16, 768, L, Hrun=Hrun)

@@ -205,48 +205,87 @@ __global__ __launch_bounds__(256) void bhl_same_kernel(const typename El<TI>::S*
   vstore<TI>(y + (size_t)row * L + l0, o);
 }
 
+// Raw (unconverted) V-element vector: lets the next iteration's loads be issued before the current one is consumed.
+template <int T> struct Raw {
+  uint4 a;
+  __device__ __forceinline__ void load(const typename El<T>::S* p) { a = *(const uint4*)p; }
+  __device__ __forceinline__ void get(float (&v)[V], bool ok) const {
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      v[2 * i] = ok ? El<T>::ld((uint16_t)(w[i] & 0xffff)) : 0.f;
+      v[2 * i + 1] = ok ? El<T>::ld((uint16_t)(w[i] >> 16)) : 0.f;
+    }
+  }
+};
+template <> struct Raw<T_F32> {
+  float4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = ((const float4*)p)[0]; b = ((const float4*)p)[1]; }
+  __device__ __forceinline__ void get(float (&v)[V], bool ok) const {
+    const float t[V] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < V; i++) v[i] = ok ? t[i] : 0.f;
+  }
+};
+
 // Fused BHL backward for "same" padding (Lout == L, P == (K-1)/2), K a compile-time constant: one pass over
-// dout and u (16-byte loads) produces du (16-byte stores) and the row's dw / dbias partial sums.
-// Replaces two passes (input gradient, then a scalar-load weight-gradient kernel): 3 tensors of traffic
-// instead of 4, and no 2-byte loads.
+// dout and u (16-byte loads) produces du (16-byte stores) and the dw / dbias partial sums.
+// A block owns channel d of NB consecutive batches (rows (b0+r)*D + d): the K+1 sums stay in registers across
+// all NB rows and leave through one reduction + K+1 atomics per block (one block per row paid that tail, a
+// barrier and 4 atomics, for every 4 loop iterations).  The walk over (row, vector) is one flat loop whose next
+// iteration's six loads are issued before the current vectors are consumed; neighbour vectors are loaded
+// unconditionally from clamped addresses and masked (no exec-mask branch per load).
 template <int TI, int TW, int K>
 __global__ __launch_bounds__(256) void bhl_bwd_kernel(const typename El<TI>::S* __restrict__ dout,
                                                       const typename El<TI>::S* __restrict__ u,
                                                       const typename El<TW>::S* __restrict__ w, typename El<TI>::S* __restrict__ du,
-                                                      float* __restrict__ dw, float* __restrict__ dbias, int D, int L) {
+                                                      float* __restrict__ dw, float* __restrict__ dbias, int B, int D, int L, int NB) {
   constexpr int P = (K - 1) / 2;
   static_assert(K - 1 <= V, "neighbour vectors cover K-1 <= V taps");
-  const int row = blockIdx.x;   // b*D + d
-  const int d = row % D;
+  const int d = blockIdx.x % D;
+  const int b0 = (blockIdx.x / D) * NB;
+  const int nrows = min(NB, B - b0);
+  const int nv = L / V;                       // vectors per row
+  const int total = nrows * nv;
   float wk[K];
 #pragma unroll
   for (int k = 0; k < K; k++) wk[k] = El<TW>::ld(w[(size_t)d * K + k]);
-  const typename El<TI>::S* dr = dout + (size_t)row * L;
-  const typename El<TI>::S* ur = u + (size_t)row * L;
-  typename El<TI>::S* dur = du + (size_t)row * L;
   float acc[K + 1];
 #pragma unroll
   for (int k = 0; k <= K; k++) acc[k] = 0.f;
-  for (int l0 = threadIdx.x * V; l0 < L; l0 += blockDim.x * V) {
+
+  Raw<TI> gq[3], xq[3];
+  auto issue = [&](int id) {
+    id = min(id, total - 1);
+    const int r = id / nv, c = id - r * nv;
+    const size_t base = ((size_t)(b0 + r) * D + d) * L;
+    const int lm = max(c - 1, 0) * V, l0 = c * V, lp = min(c + 1, nv - 1) * V;
+    gq[0].load(dout + base + lm); gq[1].load(dout + base + l0); gq[2].load(dout + base + lp);
+    xq[0].load(u + base + lm); xq[1].load(u + base + l0); xq[2].load(u + base + lp);
+  };
+  if ((int)threadIdx.x < total) issue(threadIdx.x);
+  for (int id = threadIdx.x; id < total; id += 256) {
+    const int r = id / nv, c = id - r * nv;
     float g[3 * V], x[3 * V], t[V];
-    vload<TI>(dr + l0 - V, l0 - V >= 0, t);
+    gq[0].get(t, c > 0);
 #pragma unroll
     for (int i = 0; i < V; i++) g[i] = t[i];
-    vload<TI>(dr + l0, true, t);
+    gq[1].get(t, true);
 #pragma unroll
     for (int i = 0; i < V; i++) g[V + i] = t[i];
-    vload<TI>(dr + l0 + V, l0 + 2 * V <= L, t);
+    gq[2].get(t, c + 1 < nv);
 #pragma unroll
     for (int i = 0; i < V; i++) g[2 * V + i] = t[i];
-    vload<TI>(ur + l0 - V, l0 - V >= 0, t);
+    xq[0].get(t, c > 0);
 #pragma unroll
     for (int i = 0; i < V; i++) x[i] = t[i];
-    vload<TI>(ur + l0, true, t);
+    xq[1].get(t, true);
 #pragma unroll
     for (int i = 0; i < V; i++) x[V + i] = t[i];
-    vload<TI>(ur + l0 + V, l0 + 2 * V <= L, t);
+    xq[2].get(t, c + 1 < nv);
 #pragma unroll
     for (int i = 0; i < V; i++) x[2 * V + i] = t[i];
+    if (id + 256 < total) issue(id + 256);     // next iteration's loads in flight behind this one's math + store
     float o[V];
 #pragma unroll
     for (int i = 0; i < V; i++) {
@@ -260,7 +299,7 @@ __global__ __launch_bounds__(256) void bhl_bwd_kernel(const typename El<TI>::S* 
       o[i] = s;
       acc[K] += g[V + i];
     }
-    vstore<TI>(dur + l0, o);
+    vstore<TI>(du + ((size_t)(b0 + r) * D + d) * L + c * V, o);
   }
   __shared__ float red[K + 1][4];
 #pragma unroll
@@ -633,8 +672,10 @@ int FFC_C1D_NAME(ffc_c1d_bwd_)(const void* dout, const void* u, const void* w, v
       constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
       using SI = typename El<TI>::S;
       using SW = typename El<TW>::S;
-      dim3 block(256), grid((unsigned)(B * D));
-#define FFC_L(KK) hipLaunchKernelGGL((bhl_bwd_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L)
+      // batches per block: keep >= ~8K blocks in the grid, at most 16 rows per block
+      const int NB = (int)std::max<int64_t>(1, std::min<int64_t>(16, B * D / 8192));
+      dim3 block(256), grid((unsigned)(D * ((B + NB - 1) / NB)));
+#define FFC_L(KK) hipLaunchKernelGGL((bhl_bwd_kernel<TI, TW, KK>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)B, (int)D, (int)L, NB)
       switch (K) { case 1: FFC_L(1); break; case 3: FFC_L(3); break; case 5: FFC_L(5); break; case 7: FFC_L(7); break; default: FFC_L(9); break; }
 #undef FFC_L
       hipError_t e = hipGetLastError();

@@ -15,7 +15,18 @@ from . import bigfft as _big
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
-SUPPORTED_SEQLENS = FUSED_SEQLENS + tuple(sorted(_big.BIG_FACTORS))
+# fft size 2048 has no 16/32-digit factorisation of its own: it runs on the 4096 plan with k periodised,
+# k' = [k_2048 | k_2048].  FFT_4096(k') is 2*FFT_2048(k) on the even bins and 0 on the odd ones, so the 4096-point
+# circular convolution with k' IS the 2048-point circular convolution with k (u occupies <= 2048 samples, the
+# L <= N/2 kernel variant).  dk folds back the same way: dk = dk'[:2048] + dk'[2048:].
+FOLDED_SEQLENS = {2048: 4096}
+SUPPORTED_SEQLENS = tuple(sorted(FUSED_SEQLENS + tuple(FOLDED_SEQLENS))) + tuple(sorted(_big.BIG_FACTORS))
+
+
+def _periodise_k(k, n):
+    """(H, Lk <= n) -> (H, 2n) fp32: k zero-padded to n and repeated twice."""
+    k = torch.nn.functional.pad(k.detach().to(torch.float32), (0, n - k.shape[-1]))
+    return torch.cat((k, k), dim=-1)
 
 
 class _Plan:
@@ -176,8 +187,8 @@ class _FlashFFTConvFn(torch.autograd.Function):
         if ctx.big:
             out, kf = _big_forward(mod, u, k, pregate, postgate)
         else:
-            plan = mod._get_plan(u.device)
-            kf = _kernel_fft(plan, k)
+            plan = mod._get_plan(u.device, mod._plan_seqlen)
+            kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
             out = _conv(plan, u, kf, pregate, postgate, False)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             if ctx.gated:
@@ -198,18 +209,22 @@ class _FlashFFTConvFn(torch.autograd.Function):
         if ctx.big:
             du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len)
             return du, dk.to(ctx.k_dtype), None, dpre, dpost
-        plan = ctx.mod._get_plan(u.device)
+        plan = ctx.mod._get_plan(u.device, ctx.mod._plan_seqlen)
         B, H, L = u.shape
         lib = _lib.lib()
+        k_len = plan.seqlen if ctx.mod._folded else ctx.k_len
         # one fused launch: du (and dpregate) + fp32 dk_f partial sums; then dk_f -> dk
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
         _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
                                     _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd")
-        dk = torch.empty(H, ctx.k_len, dtype=torch.float32, device=u.device)
-        _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, ctx.k_len, _lib.ptr(dk), _lib.stream_ptr()),
+        dk = torch.empty(H, k_len, dtype=torch.float32, device=u.device)
+        _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, k_len, _lib.ptr(dk), _lib.stream_ptr()),
                    "ffc_kernel_ifft_grad")
+        if ctx.mod._folded:      # chain rule of _periodise_k
+            n = ctx.mod.seqlen
+            dk = (dk[:, :n] + dk[:, n:])[:, :ctx.k_len]
         dk = dk.to(ctx.k_dtype)
         if not ctx.gated:
             return du, dk, None, None, None
@@ -227,6 +242,8 @@ class FlashFFTConv(torch.nn.Module):
         if seqlen not in SUPPORTED_SEQLENS:
             raise NotImplementedError(f"seqlen {seqlen} not supported")
         self.seqlen = seqlen
+        self._folded = seqlen in FOLDED_SEQLENS
+        self._plan_seqlen = FOLDED_SEQLENS.get(seqlen, seqlen)
         self.dtype = dtype
         self.use_32_butterfly = use_32_butterfly
         self._plans = {}

@@ -10,7 +10,7 @@ import torch
 from oracle.torch_ref import ref_fft_conv
 
 pytestmark = pytest.mark.gpu
-SEQLENS = [256, 512, 1024, 4096, 8192, 16384, 32768]
+SEQLENS = [256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
 REL = {torch.bfloat16: 2e-2, torch.float16: 5e-3}   # SURVEY.md section 8(c) gates
 
 
@@ -73,7 +73,9 @@ def run_case(B, H, seqlen, dtype, padded, gated):
     assert torch.allclose(k.grad, k_c.grad, atol=1e-1)              # reference ktol (:105-107)
     if not gated:
         assert rel(u.grad, u_c.grad) < REL[dtype]
-        assert rel(k.grad, k_c.grad) < REL[dtype]
+        # dk: SURVEY 8(c)(iii) gate is 2e-2 for both dtypes; the dk_f -> dk inverse always runs in bf16 operand
+        # arithmetic (fp32 range for the unnormalised sums), so fp16 modules see ~5e-3 there, not fp16's ~1e-3
+        assert rel(k.grad, k_c.grad) < max(REL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0))
     else:
         assert torch.allclose(pre.grad, pre_c.grad, atol=1e-2)      # reference (:242-243)
         assert torch.allclose(post.grad, post_c.grad, atol=1e-2)

@@ -48,3 +48,18 @@ def test_reference_monarch_3stage_equals_fft(N, n1, n2):
     rng = np.random.default_rng(N)
     u = rng.standard_normal((1, 2, N // 2)); k = rng.standard_normal((2, N // 2))
     assert rel(M.monarch_conv_3stage(u, k, N, n1, n2), O.ref_fft_conv(u, k, N)) < 1e-10
+
+
+@pytest.mark.parametrize("L,Lk", [(2048, 2048), (1024, 700), (2048, 1)])
+def test_fft2048_fold_identity(L, Lk):
+    """flashfftconv/conv.py FOLDED_SEQLENS: the 2048-point circular convolution equals the 4096-point one with
+    k periodised ([k_2048 | k_2048]); dk folds back as dk'[:2048] + dk'[2048:]."""
+    rng = np.random.default_rng(L + Lk)
+    u = rng.standard_normal((2, 3, L)); k = rng.standard_normal((3, Lk)); dout = rng.standard_normal((2, 3, L))
+    kp = np.zeros((3, 2048)); kp[:, :Lk] = k
+    k2 = np.concatenate([kp, kp], -1)
+    assert rel(O.ref_fft_conv(u, k2, 4096), O.ref_fft_conv(u, k, 2048)) < 1e-12
+    du, dk = O.ref_grads(u, k, dout, 2048)
+    du2, dk2 = O.ref_grads(u, k2, dout, 4096)
+    assert rel(du2, du) < 1e-12
+    assert rel((dk2[:, :2048] + dk2[:, 2048:])[:, :Lk], dk) < 1e-12
