@@ -97,6 +97,13 @@ extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t
   int64_t zs = p->hp.N1 > 1 ? hpad * nchunk * upw * (int64_t)p->hp.N * 4 : 0;
   return slabs + zs;
 }
+// number of fp32 partial-sum slabs [slab][H][kf_elems][2] at the start of the workspace (k_f's internal order)
+extern "C" int64_t ffc_dkf_slab_count(const ffc_plan* p, int64_t B, int64_t H) {
+  if (!p) return 0;
+  int nchunk, ppc;
+  ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
+  return (int64_t)nchunk * (8 / p->hp.NW);
+}
 static void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk) {
   int upw = 8 / p->hp.NW;
   return (uint8_t*)ws + (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;

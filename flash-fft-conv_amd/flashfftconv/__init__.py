@@ -2,6 +2,7 @@
 (/root/reference/flashfftconv/__init__.py:1-2)."""
 from .conv import FlashFFTConv
 from .depthwise_1d import FlashDepthWiseConv1d
+from .sparse_conv import PartialFFTConv, FrequencySparseFFTConv
 
 FlashDepthwiseConv1d = FlashDepthWiseConv1d  # README spelling of the reference
-__all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d"]
+__all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d", "PartialFFTConv", "FrequencySparseFFTConv"]

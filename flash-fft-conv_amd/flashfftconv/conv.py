@@ -189,6 +189,8 @@ class _FlashFFTConvFn(torch.autograd.Function):
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
             kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
+            if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py)
+                kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
             out = _conv(plan, u, kf, pregate, postgate, False)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             if ctx.gated:
@@ -219,6 +221,12 @@ class _FlashFFTConvFn(torch.autograd.Function):
         dpre = torch.empty_like(u) if ctx.gated else None
         _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
                                     _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd")
+        if ctx.mod._kf_keep is not None:
+            # d/dk of (mask * FFT(k)): mask the fp32 dk_f partial sums (same internal order as k_f) before the inverse
+            nfl = H * plan.kf_elems * 2
+            slabs = ws[: (ws.numel() // 4 // nfl) * nfl * 4].view(torch.float32).view(-1, H, plan.kf_elems, 2)
+            nslab = lib.ffc_dkf_slab_count(plan.handle, B, H)
+            slabs[:nslab].mul_(ctx.mod._kf_mask(plan, torch.float32)[None, None, :, None])
         dk = torch.empty(H, k_len, dtype=torch.float32, device=u.device)
         _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, k_len, _lib.ptr(dk), _lib.stream_ptr()),
                    "ffc_kernel_ifft_grad")
@@ -247,6 +255,23 @@ class FlashFFTConv(torch.nn.Module):
         self.dtype = dtype
         self.use_32_butterfly = use_32_butterfly
         self._plans = {}
+        self._kf_keep = None        # frequency-sparse mode: keep bins |f| < _kf_keep (set by sparse_conv)
+        self._masks = {}
+
+    def _kf_mask(self, plan, dtype):
+        """0/1 mask over k_f's internal positions keeping the natural frequencies |f| < self._kf_keep."""
+        key = (id(plan), dtype, self._kf_keep)
+        m = self._masks.get(key)
+        if m is None:
+            import numpy as np
+            idx = np.empty(plan.kf_elems, dtype=np.int32)
+            _lib.check(_lib.lib().ffc_plan_kf_index(plan.handle, idx.ctypes.data_as(ctypes.c_void_p)), "ffc_plan_kf_index")
+            f = idx.astype(np.int64)
+            N = plan.seqlen
+            keep = (f >= 0) & ((f < self._kf_keep) | (f > N - self._kf_keep))
+            m = torch.from_numpy(keep.astype(np.float32)).to(device=plan.device, dtype=dtype)
+            self._masks[key] = m
+        return m
 
     def _get_plan(self, device, N=None):
         N = self.seqlen if N is None else N

@@ -49,6 +49,9 @@ int ffc_conv_fwd(const ffc_plan* plan, const void* u, const void* kf, const void
 /* dk_f accumulation: dkf[h, :] (fp32 complex, internal order, scaled) = sum_b FFT(dout*postgate) * conj(FFT(u*pregate)).
  * ws: workspace of ffc_dkf_workspace_bytes() bytes (partial sums per chunk of batch pairs). */
 int64_t ffc_dkf_workspace_bytes(const ffc_plan* plan, int64_t B, int64_t H);
+/* The workspace starts with ffc_dkf_slab_count() fp32 slabs [slab][H][kf_elems][2] in k_f's internal order
+ * (frequency-sparse convolutions mask them before ffc_kernel_ifft_grad; reference flashfftconv/sparse_conv.py:24-38). */
+int64_t ffc_dkf_slab_count(const ffc_plan* plan, int64_t B, int64_t H);
 int ffc_conv_bwd_dkf(const ffc_plan* plan, const void* dout, const void* u, const void* pregate, const void* postgate,
                      void* ws, int64_t B, int64_t H, int64_t L, void* stream);
 /* Fused backward (one launch): du = pregate * corr(dout*postgate, k), dpre = u * corr(...) (nullable) and the

@@ -32,7 +32,8 @@ def main():
     cases = [  # (N, L, B, H, dtype, gated)
         (256, 256, 3, 4, torch.bfloat16, False), (256, 128, 2, 4, torch.float16, True),
         (512, 512, 2, 3, torch.bfloat16, True), (1024, 512, 4, 8, torch.bfloat16, False),
-        (1024, 1024, 2, 2, torch.float16, False), (4096, 2048, 3, 2, torch.bfloat16, True),
+        (1024, 1024, 2, 2, torch.float16, False), (2048, 2048, 2, 3, torch.bfloat16, False),
+        (2048, 1024, 3, 2, torch.float16, True), (4096, 2048, 3, 2, torch.bfloat16, True),
         (4096, 4096, 2, 2, torch.float16, False), (8192, 4096, 2, 2, torch.bfloat16, False),
         (16384, 8192, 2, 2, torch.bfloat16, True), (32768, 16384, 2, 2, torch.bfloat16, False),
         (32768, 32768, 1, 2, torch.float16, True),
@@ -65,6 +66,30 @@ def main():
                      dpre=pre.grad.float().numpy(), dpost=post.grad.float().numpy())
         name = f"conv_N{N}_L{L}_B{B}_H{H}_{d['dtype']}_{'gated' if gated else 'plain'}.npz"
         np.savez_compressed(os.path.join(OUT, name), **d)
+        print("wrote", name)
+    sparse_golden()
+
+
+def sparse_golden():
+    """Partial / frequency-sparse convolutions: the reference's own module source
+    (/root/reference/flashfftconv/sparse_conv.py:8-38), loaded by file path (it only needs torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_sparse_conv", os.path.join(REF, "flashfftconv/sparse_conv.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    for (kind, L, Np, B, H, dtype) in [("partial", 1024, 256, 2, 3, torch.bfloat16), ("partial", 4096, 1000, 2, 2, torch.float16),
+                                       ("freqsparse", 1024, 512, 2, 3, torch.bfloat16), ("freqsparse", 2048, 1024, 2, 2, torch.float16),
+                                       ("freqsparse", 16384, 4096, 1, 2, torch.bfloat16)]:
+        g = torch.Generator().manual_seed(L + Np)
+        x = torch.randn(B, H, L, generator=g).to(dtype).requires_grad_(True)
+        k = (torch.randn(H, L, generator=g) * 0.1 * torch.exp(-0.01 * torch.arange(L))).requires_grad_(True)
+        dout = torch.randn(B, H, L, generator=g).to(dtype)
+        mod = (m.PartialFFTConv if kind == "partial" else m.FrequencySparseFFTConv)(Np)
+        out = mod(x, k)
+        out.backward(dout)
+        name = f"sparse_{kind}_L{L}_P{Np}_B{B}_H{H}_{str(dtype).split('.')[-1]}.npz"
+        np.savez_compressed(os.path.join(OUT, name), kind=kind, L=L, N_partial=Np, dtype=str(dtype).split(".")[-1],
+                            x=x.detach().float().numpy(), k=k.detach().numpy(), dout=dout.float().numpy(),
+                            out=out.detach().float().numpy(), dx=x.grad.float().numpy(), dk=k.grad.numpy())
         print("wrote", name)
 
 

@@ -223,3 +223,24 @@ def test_full_size_properties_config2():
     lhs = conv((a.float() + b2.float()).to(torch.bfloat16), k).float()
     rhs = conv(a, k).float() + conv(b2, k).float()
     assert rel(lhs, rhs) < 1.5e-2
+
+
+SPARSE = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sparse_*.npz")))
+
+
+@pytest.mark.parametrize("path", SPARSE, ids=[os.path.basename(p)[7:-4] for p in SPARSE])
+def test_sparse_conv_golden(path):
+    """PartialFFTConv / FrequencySparseFFTConv on the HIP path vs vectors from the reference's own
+    flashfftconv/sparse_conv.py (oracle/make_golden.py: sparse_golden)."""
+    from flashfftconv import PartialFFTConv, FrequencySparseFFTConv
+    g = np.load(path)
+    dtype = getattr(torch, str(g["dtype"]))
+    t = lambda n, dt: torch.tensor(g[n], device="cuda").to(dt)
+    x, k = t("x", dtype).requires_grad_(True), t("k", torch.float32).requires_grad_(True)
+    mod = (PartialFFTConv if str(g["kind"]) == "partial" else FrequencySparseFFTConv)(int(g["N_partial"]))
+    out = mod(x, k)
+    out.backward(t("dout", dtype))
+    tol = REL[dtype]
+    assert rel(out, t("out", torch.float32)) < tol
+    assert rel(x.grad, t("dx", torch.float32)) < tol
+    assert rel(k.grad, t("dk", torch.float32)) < max(tol, 1e-2)

@@ -63,3 +63,25 @@ def test_fft2048_fold_identity(L, Lk):
     du2, dk2 = O.ref_grads(u, k2, dout, 4096)
     assert rel(du2, du) < 1e-12
     assert rel((dk2[:, :2048] + dk2[:, 2048:])[:, :Lk], dk) < 1e-12
+
+
+SPARSE = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "sparse_*.npz")))
+
+
+@pytest.mark.parametrize("path", SPARSE, ids=[os.path.basename(p)[7:-4] for p in SPARSE])
+def test_oracle_matches_reference_sparse_golden(path):
+    """oracle restatement of the reference's PartialFFTConv / FrequencySparseFFTConv vs vectors produced by the
+    reference's own module (oracle/make_golden.py: sparse_golden)."""
+    g = np.load(path)
+    dt, Np = DT[str(g["dtype"])], int(g["N_partial"])
+    tol = 6e-3 if dt == "bf16" else 8e-4
+    if str(g["kind"]) == "partial":
+        out = O.ref_partial_conv(g["x"], g["k"], Np)
+        kt = g["k"].copy(); kt[..., Np:] = 0
+        dx, dk = O.ref_grads(g["x"], kt, g["dout"], 2 * int(g["L"]))
+        dk[..., Np:] = 0
+    else:
+        out, dx, dk = O.ref_freq_sparse_conv(g["x"], g["k"], Np, g["dout"])
+    assert rel(out, g["out"].astype(np.float64)) < tol
+    assert rel(dx, g["dx"].astype(np.float64)) < 2 * tol
+    assert rel(dk, g["dk"].astype(np.float64)) < 2 * tol
