@@ -90,6 +90,10 @@ int ffc_conv1d_bwd(const void* dout, const void* u, const void* w, void* du, flo
 int ffc_conv_fwd_prof(const ffc_plan* plan, const void* u, const void* kf, void* y, int64_t B, int64_t H, int64_t L,
                       unsigned long long* prof, int* grid_out, void* stream);
 
+/* Test support: fills every CU's LDS and vector/accumulation registers with NaN patterns (a kernel that reads
+ * state it never initialised then fails loudly instead of inheriting the previous workgroup's benign leftovers). */
+int ffc_debug_poison(void* stream);
+
 /* Hardware-primitive self test (MFMA lane layouts, ds_read_b64_tr_b16, packing): fills `out_host`
  * (host memory, 64*40 uint32) for comparison against the CPU wave simulator.  Test support. */
 int ffc_selftest_primitives(const uint32_t* in_host, uint32_t* out_host);

@@ -44,6 +44,21 @@ def make_inputs(B, H, L, N, dtype, half_zero, device="cuda"):
     return u, k
 
 
+def stable(fn, what, tries=5):
+    """torch.fft (rocFFT) reference, computed until two consecutive evaluations agree bitwise.
+    Observed on the MI355X boxes while the GPU is time-sliced between processes (pytest-xdist): torch.fft
+    transiently returns whole (b, h) rows that are off by 1e-3..2e-2 relative, in ~5 % of the cases, on either of two
+    back-to-back identical calls; the HIP kernels were bitwise reproducible in all of the same runs (asserted
+    below).  A reference that flickers must not decide a parity test, so it has to reproduce itself first."""
+    prev = fn()
+    for _ in range(tries):
+        cur = fn()
+        if all(torch.equal(a, b) for a, b in zip(prev, cur)):
+            return cur
+        prev = cur
+    pytest.fail(f"torch.fft reference ({what}) never reproduced itself in {tries + 1} evaluations")
+
+
 def run_case(B, H, seqlen, dtype, padded, gated):
     from flashfftconv import FlashFFTConv
     # big sizes add two bf16/fp16 roundings per outer level (through HBM) on each side
@@ -59,28 +74,38 @@ def run_case(B, H, seqlen, dtype, padded, gated):
     if gated:
         pre = (torch.randn_like(u) * 0.02).requires_grad_(True); post = (torch.randn_like(u) * 0.02).requires_grad_(True)
         pre_c, post_c = pre.detach().clone().requires_grad_(True), post.detach().clone().requires_grad_(True)
-        ref = ref_fft_conv(u_c * pre_c, k_c, n=N) * post_c
+        leaves_c = (u_c, k_c, pre_c, post_c)
+        (ref,) = stable(lambda: (ref_fft_conv(u_c * pre_c, k_c, n=N) * post_c,), "forward")
         out = conv(u, k, pre, post)
     else:
-        ref = ref_fft_conv(u_c, k_c, n=N)
+        leaves_c = (u_c, k_c)
+        (ref,) = stable(lambda: (ref_fft_conv(u_c, k_c, n=N),), "forward")
         out = conv(u, k)
+    with torch.no_grad():       # the HIP side must be bitwise reproducible run to run
+        out_b = conv(u, k, pre, post) if gated else conv(u, k)
+    assert torch.equal(out, out_b), f"HIP forward not reproducible: {int((out != out_b).sum())} elements differ"
     assert torch.allclose(out, ref, atol=1e-2)                      # reference assert (:83)
     if not gated:
         assert rel(out, ref) < REL[dtype]
     dout = torch.randn_like(out) * 0.02
-    ref.backward(dout.clone()); out.backward(dout)
-    assert torch.allclose(u.grad, u_c.grad, atol=1e-2)              # reference assert (:103)
-    assert torch.allclose(k.grad, k_c.grad, atol=1e-1)              # reference ktol (:105-107)
+    gref = stable(lambda: torch.autograd.grad(ref, leaves_c, dout.clone(), retain_graph=True), "backward")
+    leaves = (u, k, pre, post) if gated else (u, k)
+    g = torch.autograd.grad(out, leaves, dout, retain_graph=True)
+    g_b = torch.autograd.grad(out, leaves, dout)
+    for name, a, b in zip(("du", "dk", "dpregate", "dpostgate"), g, g_b):
+        assert torch.equal(a, b), f"HIP backward ({name}) not reproducible: {int((a != b).sum())} elements differ"
+    assert torch.allclose(g[0], gref[0], atol=1e-2)                 # reference assert (:103)
+    assert torch.allclose(g[1], gref[1], atol=1e-1)                 # reference ktol (:105-107)
     if not gated:
-        assert rel(u.grad, u_c.grad) < REL[dtype]
+        assert rel(g[0], gref[0]) < REL[dtype]
         # dk: SURVEY 8(c)(iii) gate is 2e-2 for both dtypes; the dk_f -> dk inverse always runs in bf16 operand
         # arithmetic (fp32 range for the unnormalised sums), so fp16 modules see ~5e-3 there, not fp16's ~1e-3
-        assert rel(k.grad, k_c.grad) < max(REL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0))
+        assert rel(g[1], gref[1]) < max(REL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0))
     else:
-        assert torch.allclose(pre.grad, pre_c.grad, atol=1e-2)      # reference (:242-243)
-        assert torch.allclose(post.grad, post_c.grad, atol=1e-2)
+        assert torch.allclose(g[2], gref[2], atol=1e-2)             # reference (:242-243)
+        assert torch.allclose(g[3], gref[3], atol=1e-2)
         # *0.02 gates make fp16 outputs subnormal; relative gates use the fp32 reference scale
-        assert rel(k.grad, k_c.grad) < 2 * REL[dtype]
+        assert rel(g[1], gref[1]) < 2 * REL[dtype]
 
 
 @pytest.mark.parametrize("seqlen", SEQLENS)

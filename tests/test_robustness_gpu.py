@@ -1,0 +1,18 @@
+"""Robustness of the HIP path against state it does not own (run as scripts so that torch.empty can be patched
+process-wide): results must not depend on (a) what the previous workgroup left in a CU's LDS / vector / accumulation
+registers (tests/gpu_poison.py, ffc_debug_poison) or (b) the previous contents of any buffer the Python layer
+allocates (tests/gpu_uninit.py pre-fills every torch.empty with NaN bit patterns)."""
+import os, subprocess, sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("script,done", [("gpu_poison.py", "poison stress done, mismatching tensors: 0"),
+                                         ("gpu_uninit.py", "uninit hunt done, mismatching tensors: 0")])
+def test_script(script, done):
+    r = subprocess.run([sys.executable, os.path.join(HERE, script)], capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert done in r.stdout, tail
