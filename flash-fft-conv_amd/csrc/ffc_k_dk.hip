@@ -26,7 +26,7 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   DkArgs a{};
   // always bf16 arithmetic: W/N underflows fp16 for small gradients, bf16 keeps fp32's range
   a.ws = (const float*)ws; a.dk = dk; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = (int)Lk;
-  a.nslab = nchunk * (8 / p->hp.NW);
+  a.nslab = nchunk * ffc_slabs_per_chunk(p);
   a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
   if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
@@ -41,6 +41,6 @@ extern "C" int ffc_kernel_ifft_grad_c(const ffc_plan* p, const void* ws, int64_t
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   DkArgs a{};
   a.ws = (const float*)ws; a.outpair = outpair; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = p->hp.N;
-  a.nslab = nchunk * (8 / p->hp.NW); a.scale = scale; a.s_inv = (float)p->hp_bf.s_inv; a.fast = 1;
+  a.nslab = nchunk * ffc_slabs_per_chunk(p); a.scale = scale; a.s_inv = (float)p->hp_bf.s_inv; a.fast = 1;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }

@@ -91,7 +91,7 @@ extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   int upw = 8 / p->hp.NW;
-  int64_t slabs = (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
+  int64_t slabs = (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.NT * 2048 * 4;
   // + spectrum scratch: one N-point dtype-complex slot per (workgroup, unit) of the grid
   int64_t hpad = (H + 7) & ~(int64_t)7;
   int64_t zs = p->hp.N1 > 1 ? hpad * nchunk * upw * (int64_t)p->hp.N * 4 : 0;
@@ -102,11 +102,10 @@ extern "C" int64_t ffc_dkf_slab_count(const ffc_plan* p, int64_t B, int64_t H) {
   if (!p) return 0;
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
-  return (int64_t)nchunk * (8 / p->hp.NW);
+  return (int64_t)nchunk * ffc_slabs_per_chunk(p);
 }
 static void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk) {
-  int upw = 8 / p->hp.NW;
-  return (uint8_t*)ws + (int64_t)nchunk * upw * H * p->hp.NT * 2048 * 4;
+  return (uint8_t*)ws + (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.NT * 2048 * 4;
 }
 
 extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void* u, const void* pregate, const void* postgate,

@@ -395,6 +395,58 @@ struct Modes : Body<B, GEO, DT> {
       w_acc_store_t<2>(slab, tau0, hi, c); w_acc_store_t<3>(slab, tau0, hi, c);
     }
   }
+  // Cross-unit reduction of the accumulation registers (UPW > 1: the UPW units of a workgroup are UPW pairs of the
+  // SAME head, each with its own W in a0..a127).  Per tile: every wave parks its 32 accumulators in the (now idle)
+  // exchange buffers, [wave][register][lane] fp32; after a barrier the UPW waves that share a tile each sum one
+  // 1/UPW share over the units in a fixed order (bitwise reproducible) and write it to the chunk's single slab.
+  // One slab per chunk instead of UPW: 8x less dk_f traffic at fft 4096 (written here, read back by dkifft).
+  template <int T, int R0, int NR>
+  static FFC_FN void w_acc_park(i32 base) {
+    if constexpr (NR == 1) B::lds_w32(base + R0 * 256, B::as_u32(B::template agpr_get<32 * T + R0>()));
+    else { w_acc_park<T, R0, NR / 2>(base); w_acc_park<T, R0 + NR / 2, NR - NR / 2>(base); }
+  }
+  template <int T>
+  static FFC_FN void w_acc_reduce_tile(float* slab, int tau0, int u, int wq, i32 lane) {
+    const i32 c = lane & 31, hi = lane >> 5;
+    w_acc_park<T, 0, 32>(GEO::L_E + (u * GEO::NW + wq) * 8192 + lane * 4);
+    B::barrier();
+    constexpr int SPW = 8 / GEO::UPW;          // (RQ, j) slots of 2 complex values per wave
+#pragma unroll
+    for (int qq = 0; qq < SPW; qq++) {
+      const int q = u * SPW + qq;
+      const int RQ = q >> 1, j = q & 1;
+      const int r0 = 4 * RQ + 2 * j;
+      f32 sre0 = B::fconst(0.f), sre1 = B::fconst(0.f), sim0 = B::fconst(0.f), sim1 = B::fconst(0.f);
+#pragma unroll
+      for (int s2 = 0; s2 < GEO::UPW; s2++) {
+        const i32 src = GEO::L_E + (s2 * GEO::NW + wq) * 8192 + lane * 4;
+        sre0 = sre0 + B::as_f32(B::lds_r32(src + r0 * 256));
+        sre1 = sre1 + B::as_f32(B::lds_r32(src + (r0 + 1) * 256));
+        sim0 = sim0 + B::as_f32(B::lds_r32(src + (16 + r0) * 256));
+        sim1 = sim1 + B::as_f32(B::lds_r32(src + (17 + r0) * 256));
+      }
+      U4 n;
+      n.x = B::as_u32(sre0); n.y = B::as_u32(sim0); n.z = B::as_u32(sre1); n.w = B::as_u32(sim1);
+      i32 idx = ((hi + ((tau0 + T) * 8 + 2 * RQ)) * 32 + c) * 2 + j;
+      B::g_w128(slab, idx, n, B::ptrue());
+    }
+    B::barrier();
+  }
+  // end of a chunk (OUTER geometries): `slab` is the chunk's single slab of this head, [chunk][H][NT*2048] floats
+  static FFC_FN void w_acc_finish(float* slab, int u, Unit un, const WAcc& W) {
+    if constexpr (GEO::UPW == 1) {
+      w_acc_store(slab, un.wq * GEO::TPW, W);
+    } else {
+      static_assert(WREG == GEO::TPW, "the per-pair slab path (FFC_WREG=0) only exists for one unit per workgroup");
+      static_assert(GEO::UPW * GEO::NW * 8192 <= GEO::UPW * GEO::EBYTES, "parking area fits the exchange buffers");
+      const i32 lane = B::opaque(B::lane());
+      B::barrier();
+      w_acc_reduce_tile<0>(slab, un.wq * GEO::TPW, u, un.wq, lane);
+      w_acc_reduce_tile<1>(slab, un.wq * GEO::TPW, u, un.wq, lane);
+      w_acc_reduce_tile<2>(slab, un.wq * GEO::TPW, u, un.wq, lane);
+      w_acc_reduce_tile<3>(slab, un.wq * GEO::TPW, u, un.wq, lane);
+    }
+  }
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
   // accumulator registers are addressed statically.
@@ -443,7 +495,8 @@ struct Modes : Body<B, GEO, DT> {
     ConvArgs av = a;            // v = u * pregate
     ConvArgs ad = a;            // dc = dout * postgate
     ad.u = d.dout; ad.pregate = a.postgate;
-    float* slab = d.ws + ((int64_t)(chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit)
+    float* slab = d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -485,7 +538,7 @@ struct Modes : Body<B, GEO, DT> {
         }
         B::barrier();
       }
-      w_acc_store(slab, un.wq * GEO::TPW, W);
+      w_acc_finish(slab, u, un, W);
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
@@ -556,7 +609,8 @@ struct Modes : Body<B, GEO, DT> {
     ao.y = d.du; ao.postgate = a.pregate;
     ConvArgs ap = a;            // dpre = dv * u
     ap.y = d.dpre; ap.postgate = a.u;
-    float* slab = d.ws + ((int64_t)(chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit)
+    float* slab = d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -606,7 +660,7 @@ struct Modes : Body<B, GEO, DT> {
           if (d.dpre) BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ap, h, p, un);
         }
       }
-      w_acc_store(slab, un.wq * GEO::TPW, W);
+      w_acc_finish(slab, u, un, W);
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;

@@ -1,0 +1,11 @@
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01g; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest_single.log 2>&1; tail -3 $O/pytest_single.log | cut -c1-200
+python benchmarks/sweep.py all 2>&1 | grep -v amdgpu.ids > $O/sweep.jsonl
+python - <<PY
+import json
+for l in open("$O/sweep.jsonl"):
+    r = json.loads(l); print(r["row"], r.get("fwd_ms"), r.get("bwd_ms"))
+PY
+python bench.py --no-cpu-baseline 2> /dev/null | cut -c1-900
