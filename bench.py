@@ -160,8 +160,8 @@ def main():
             "achieved": alg_flops / t_conv / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": alg_flops / t_conv / 1e12 / MFMA_PEAK_TFLOPS,
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-            # profiles/r01_final_pmc_conv_kernel.txt; not re-measured inside bench.py
-            "traffic": 1611.6e6, "traffic_source": "profiles/r01_final_pmc_conv_kernel.txt",
+            # profiles/r01_end_pmc_conv_kernel.txt; not re-measured inside bench.py
+            "traffic": 1611.6e6, "traffic_source": "profiles/r01_end_pmc_conv_kernel.txt",
             "launch_ms": t_conv * 1e3,
             "hbm_GBs": alg_bytes / t_conv / 1e9, "hbm_frac": alg_bytes / t_conv / 1e9 / HBM_PEAK_GBS,
             "basis": "SURVEY 8(d): dense Monarch 42.9 MFLOP/row (reference 32x32x32 factorisation) x rows; our pair-packed kernel executes ~half of these"}

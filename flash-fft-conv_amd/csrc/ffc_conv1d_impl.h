@@ -457,7 +457,7 @@ int launch_fwd(const void* u, const void* w, const void* bias, void* y, int64_t 
   return 0;
 }
 
-// Fused BLH backward for "same" padding, K in {3, 5}: a thread owns V channels and walks a slab of consecutive
+// Fused BLH backward for "same" padding, K in {3, 5, 7}: a thread owns V channels and walks a slab of consecutive
 // positions of one batch with K-row sliding windows of dout and u in registers (slot = row mod K, static after
 // unrolling by K): every row of dout / u is loaded once (16 bytes per lane, 1 KiB per wave), du is stored as it
 // goes, dw / dbias sums leave through one fp32 atomic per value at the end of the slab.
@@ -683,8 +683,8 @@ int FFC_C1D_NAME(ffc_c1d_bwd_)(const void* dout, const void* u, const void* w, v
     });
     return rc;
   }
-  // BLH, "same" padding, K in {3,5}, aligned channel vectors: one fused pass
-  if (!is_bhl && Lout == L && 2 * P == K - 1 && (K == 3 || K == 5) && D % V == 0 &&
+  // BLH, "same" padding, K in {3,5,7}, aligned channel vectors: one fused pass
+  if (!is_bhl && Lout == L && 2 * P == K - 1 && (K == 3 || K == 5 || K == 7) && D % V == 0 &&
       !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)du | (uintptr_t)w) & 15)) {
     return by_dtypes(in_dtype, w_dtype, [&](auto ti, auto tw) {
       constexpr int TI = decltype(ti)::value, TW = decltype(tw)::value;
@@ -696,7 +696,8 @@ int FFC_C1D_NAME(ffc_c1d_bwd_)(const void* dout, const void* u, const void* w, v
       if (B * slabs > 65535) return fail1d("grid too large");
       dim3 block(64), grid((unsigned)((D / V + 63) / 64), (unsigned)(B * slabs));
       if (K == 3) hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 3>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
-      else hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 5>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
+      else if (K == 5) hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 5>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
+      else hipLaunchKernelGGL((blh_bwd_kernel<TI, TW, 7>), grid, block, 0, (hipStream_t)stream, (const SI*)dout, (const SI*)u, (const SW*)w, (SI*)du, dw, dbias, (int)D, (int)L, R);
       hipError_t e = hipGetLastError();
       return e == hipSuccess ? 0 : fail1d(hipGetErrorString(e));
     });
