@@ -41,6 +41,7 @@ struct ConvArgs {
   float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
   float s_fwd;           // forward scale, applied with the outer forward twiddle (fused sizes >= 4096)
   int flags;             // reserved tuning flags
+  int persist;           // grid cap of the persistent one-wave-per-unit kernels (CU count rounded down to 8)
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -900,6 +901,14 @@ struct Body {
   // Job loop of the fused sizes.  HALF (32-point outer digit, L <= N/2): only E rows < 16 carry input and
   // only result rows < 16 are stored, so half of the row traffic is skipped and the next pair's rows fit in
   // 32 VGPRs: they are prefetched right after phase A and written to E after rows_out of the current pair.
+  // Phase boundary of one unit.  A unit that is handled by a single wave (NW == 1: fft 4096) owns its exchange
+  // buffer alone, so its phases only need program order (LDS operations of one wave retire in order): the eight
+  // waves of the workgroup are then free to drift apart, one unit's global loads / stores overlap another's math
+  // instead of all eight meeting at every phase boundary.
+  static FFC_FN void unit_barrier() {
+    if constexpr (GEO::NW > 1) B::barrier();
+    else B::lds_fence();
+  }
   template <bool HALF, bool PROF = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
@@ -929,7 +938,7 @@ struct Body {
         outer_stage<true, HALF>(a.L, un, a.s_fwd);
         FFC_TICK(1)
       }
-      B::barrier();
+      unit_barrier();
       FFC_TICK(2)
       if (act) {
         // no long-latency global load may be outstanding while a phase runs: vmcnt retires in order, so
@@ -952,7 +961,7 @@ struct Body {
         }
       }
       FFC_TICK(3)
-      B::barrier();
+      unit_barrier();
       FFC_TICK(4)
       if (PREFETCH && it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
       if (act) {
@@ -978,6 +987,11 @@ struct Body {
   template <bool HALF = false>
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
     setup_tables(a.tab, a.t);
+    conv_job<HALF>(a, h, chunk);
+  }
+  // one (head, chunk) job; the tables are already in LDS
+  template <bool HALF = false>
+  static FFC_FN void conv_job(const ConvArgs& a, int h, int chunk) {
     const int wv = B::wave();
     Unit un;
     un.wq = wv % GEO::NW;

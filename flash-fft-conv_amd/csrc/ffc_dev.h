@@ -205,6 +205,12 @@ struct DevB {
 
 // blockIdx -> (head, chunk).  Blocks land on XCD (id % 8): keep all chunks of one head on one XCD
 // so k_f[h] is served by that XCD's L2 (speed only, never correctness).
+__device__ __forceinline__ bool map_id(int id, int H, int nchunk, int* h, int* chunk) {
+  int xcd = id & 7, s = id >> 3;
+  *h = xcd + 8 * (s / nchunk);
+  *chunk = s % nchunk;
+  return *h < H;
+}
 __device__ __forceinline__ bool map_block(int H, int nchunk, int* h, int* chunk) {
   int id = blockIdx.x;
   int xcd = id & 7, s = id >> 3;

@@ -4,24 +4,40 @@ using namespace ffc;
 
 template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
-  int h, chunk;
-  if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
-  Body<DevB, GEO, DT>::template conv<HALF>(a, h, chunk);
+  using BD = Body<DevB, GEO, DT>;
+  if constexpr (GEO::OUTER && GEO::NW == 1) {
+    // One wave per unit (fft 4096): persistent workgroups, one per CU, walk the (head, chunk) jobs with a stride of
+    // the grid (a multiple of 8, so a workgroup's heads stay on its XCD).  No phase of these units needs a
+    // workgroup barrier (Body::unit_barrier), so the eight waves drift apart across jobs: one wave's row loads and
+    // stores overlap another's transforms, and the plan tables are copied to LDS once per CU instead of once per head.
+    BD::setup_tables(a.tab, a.t);
+    const int total = ((a.H + 7) & ~7) * a.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF>(a, h, chunk);
+    }
+  } else {
+    int h, chunk;
+    if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
+    BD::template conv<HALF>(a, h, chunk);
+  }
 }
 
 template <class GEO, int DT>
 struct ConvLaunch {
   static int run(const ConvArgs& a, hipStream_t st) {
     int hpad = (a.H + 7) & ~7;
+    int grid = hpad * a.nchunk;
+    if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
     if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= a.L) {
       static int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((conv_kernel<GEO, DT, true>), dim3(hpad * a.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+      hipLaunchKernelGGL((conv_kernel<GEO, DT, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
     } else {
       static int rc = ffc_set_lds(conv_kernel<GEO, DT, false>, GEO::LDS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((conv_kernel<GEO, DT, false>), dim3(hpad * a.nchunk), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+      hipLaunchKernelGGL((conv_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel launch: ") + hipGetErrorString(e));
@@ -45,6 +61,8 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  a.persist = p->num_cu & ~7;
+  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;   // tuning knob
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }
 

@@ -512,7 +512,7 @@ struct Modes : Body<B, GEO, DT> {
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
 #pragma unroll 1
@@ -522,13 +522,13 @@ struct Modes : Body<B, GEO, DT> {
             z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
           bwd_tiles<false>(a, h, un, R, zs, slab, it == 0, W);
@@ -536,7 +536,7 @@ struct Modes : Body<B, GEO, DT> {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
-        B::barrier();
+        BD::unit_barrier();
       }
       w_acc_finish(slab, u, un, W);
     } else {
@@ -628,7 +628,7 @@ struct Modes : Body<B, GEO, DT> {
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
 #pragma unroll 1
@@ -638,13 +638,13 @@ struct Modes : Body<B, GEO, DT> {
             z_store(zs, un.wq * GEO::TPW + tt, re, im);
           }
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
           B::lds_fence();
           BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
           bwd_tiles<true>(a, h, un, R, zs, slab, it == 0, W);
@@ -652,7 +652,7 @@ struct Modes : Body<B, GEO, DT> {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
-        B::barrier();
+        BD::unit_barrier();
         if (act) {
           BD::template outer_stage<false, HALF && GEO::S1 == 1>(a.L, un);
           B::lds_fence();
