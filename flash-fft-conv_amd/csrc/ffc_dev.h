@@ -88,6 +88,7 @@ struct DevB {
   // keep a load-defined MFMA operand in architectural VGPRs (the allocator may otherwise place it in the
   // accumulation registers, which hold the dk_f partial sums in the backward kernels)
   static FFC_FN void pin(W4& x) { asm("" : "+v"(x)); }
+  static FFC_FN void pin4(U4& x) { asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w)); }
   static FFC_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
   // rows r0, r0+1 of (re,im) times (t0,t1) (or its conjugate): one packed mul + one packed fma per output pair
   template <bool CONJ>

@@ -126,8 +126,20 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
 
 // Fused backward: du = pregate * corr(dout*postgate, k), dpre = u * corr(...) (nullable, gated only) and the
 // dk_f partial sums in `ws` (same layout as ffc_conv_bwd_dkf; finish with ffc_kernel_ifft_grad).
+extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
+                            int64_t B, int64_t H, int64_t L, int conj_kf, void* stream);
+extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                                  const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                                  int64_t L, void* stream);
 extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
                             const void* postgate, void* du, void* dpre, void* ws, int64_t B, int64_t H, int64_t L, void* stream) {
+  return ffc_conv_bwd_gated(p, dout, u, kf, pregate, postgate, du, dpre, nullptr, ws, B, H, L, stream);
+}
+// + dpost = dout * conv(u*pregate, k) (nullable).  Fused sizes >= 4096 produce it inside the same launch (one extra
+// inverse transform per pair); the single-tile sizes (N <= 1024) run the forward kernel with dout as the output gate.
+extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                                  const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                                  int64_t L, void* stream) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -140,5 +152,9 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
-  return ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
+  d.dpost = p->hp.N1 > 1 ? dpost : nullptr;
+  if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;
+  int rc = ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
+  if (rc || !dpost || d.dpost) return rc;
+  return ffc_conv_fwd(p, u, kf, pregate, dout, dpost, B, H, L, 0, stream);
 }

@@ -34,6 +34,9 @@ struct DkfArgs {
   // dpre = u * corr(dout*postgate, k) (nullable)
   void* du;
   void* dpre;
+  // dpost = dout * conv(u*pregate, k) (nullable; fused sizes >= 4096 only): the forward output falls out of the
+  // first spectrum of each pair (one extra inverse transform instead of a second forward launch)
+  void* dpost;
   // scratch for the first spectrum of a pair (dtype, internal order), one N-point slot per (workgroup, unit):
   // written and read back by the same wave, so it only has to survive in L2 (fused sizes >= 4096)
   void* zscratch;
@@ -577,6 +580,19 @@ struct Modes : Body<B, GEO, DT> {
   // per pair: Z_v = FFT(u*pregate); Z_d = FFT(dout*postgate); W += Z_d conj(Z_v);
   //           dv = iFFT(Z_d conj(k_f)); du = dv * pregate; dpre = dv * u.
   // (reference: kernels_bf16/monarch_cuda_*_bwd_kernel_bf16.h compute the same three transforms)
+  static FFC_FN void kf_plain_mul(const typename BD::KfRegs& kf, A16& re, A16& im) {
+    typename BD::CT16 k;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        k.re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+        k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
+      }
+    }
+    BD::cmul(re, im, k);
+  }
   static FFC_FN void kf_conj_mul(const typename BD::KfRegs& kf, A16& re, A16& im) {
     typename BD::CT16 k;
 #pragma unroll
@@ -609,6 +625,8 @@ struct Modes : Body<B, GEO, DT> {
     ao.y = d.du; ao.postgate = a.pregate;
     ConvArgs ap = a;            // dpre = dv * u
     ap.y = d.dpre; ap.postgate = a.u;
+    ConvArgs aq = a;            // dpost = conv(u*pregate, k) * dout
+    aq.y = d.dpost; aq.postgate = d.dout;
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit)
     float* slab = d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
@@ -633,12 +651,29 @@ struct Modes : Body<B, GEO, DT> {
           BD::template load_inner<false>(R, un);
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt++) {
+            const int tau = un.wq * GEO::TPW + tt;
             A16 re, im;
-            BD::template tile_fwd<false>(un.wq * GEO::TPW + tt, R, un, re, im);
-            z_store(zs, un.wq * GEO::TPW + tt, re, im);
+            BD::template tile_fwd<false>(tau, R, un, re, im);
+            z_store(zs, tau, re, im);
+            if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
+              // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
+              typename BD::KfRegs kf;
+              BD::load_kf(a, h, tau, kf);
+              kf_plain_mul(kf, re, im);
+              BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
+            }
           }
         }
         BD::unit_barrier();
+        if (d.dpost) {
+          if (act) {
+            BD::template outer_stage<false, HALF && GEO::S1 == 1>(a.L, un);
+            B::lds_fence();
+            BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(aq, h, p, un);   // dpost = y * dout
+          }
+          // no barrier: phase C, rows_out and the rows_in / phase A that follow all stay inside the wave's own
+          // column slice of E (same as between two pairs of the forward kernel)
+        }
         if (act) {
           BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
           B::lds_fence();

@@ -97,6 +97,7 @@ struct SimB {
   template <int I> static f32 agpr_get() { return g_agpr[I]; }
   template <int I> static void agpr_set(const f32& x) { g_agpr[I] = x; }
   static void pin(W4&) {}
+  static void pin4(U4&) {}
   static void sched_fence() {}
   template <bool CONJ>
   static void cmul2(A16& re, A16& im, int r0, const f32& tr0, const f32& tr1, const f32& ti0, const f32& ti1) {
@@ -479,7 +480,7 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
 
 // fused backward: du (and dpre if non-null) + dk_f slabs; returns the number of slabs
 int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
-                    void* du, void* dpre, float* ws, int B, int H, int L, int nchunk) {
+                    void* du, void* dpre, void* dpost, float* ws, int B, int H, int L, int nchunk) {
   HostPlan p;
   if (!build_plan(N, dtype, &p)) return -1;
   DkfArgs d{};
@@ -493,7 +494,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   int ipc = (iters_total + nchunk - 1) / nchunk;
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
-  d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre;
+  d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
   int rc = dispatch<BwdRun>(N, dtype, d);

@@ -32,6 +32,7 @@ def lib():
         L.ffc_dkf_slab_count.argtypes = [c_vp, c_i64, c_i64]; L.ffc_dkf_slab_count.restype = c_i64
         L.ffc_conv_bwd_dkf.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
         L.ffc_conv_bwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
+        L.ffc_conv_bwd_gated.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
         L.ffc_kernel_ifft_grad.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]
         c_f = ctypes.c_float
         L.ffc_outer_pass.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_vp]

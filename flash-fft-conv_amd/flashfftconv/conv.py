@@ -29,6 +29,10 @@ def _periodise_k(k, n):
     return torch.cat((k, k), dim=-1)
 
 
+def _kf_key(k):
+    return (k.data_ptr(), k._version, tuple(k.shape), k.dtype, k.device)
+
+
 class _Plan:
     """Owns an ffc_plan (DFT tiles + twiddles on the device) for one (fft size, dtype, device)."""
 
@@ -188,9 +192,13 @@ class _FlashFFTConvFn(torch.autograd.Function):
             out, kf = _big_forward(mod, u, k, pregate, postgate)
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
-            kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
-            if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py)
-                kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
+            kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None
+            if kf is None:
+                kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
+                if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py)
+                    kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
+                if mod.cache_kf and not k.requires_grad:
+                    mod._kf_cache = (_kf_key(k), kf)
             out = _conv(plan, u, kf, pregate, postgate, False)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             if ctx.gated:
@@ -215,12 +223,14 @@ class _FlashFFTConvFn(torch.autograd.Function):
         B, H, L = u.shape
         lib = _lib.lib()
         k_len = plan.seqlen if ctx.mod._folded else ctx.k_len
-        # one fused launch: du (and dpregate) + fp32 dk_f partial sums; then dk_f -> dk
+        # one fused launch: du (+ dpregate, dpostgate when gated) + fp32 dk_f partial sums; then dk_f -> dk
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
-        _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
-                                    _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(ws), B, H, L, _lib.stream_ptr()), "ffc_conv_bwd")
+        dpost = torch.empty_like(u) if ctx.gated else None
+        _lib.check(lib.ffc_conv_bwd_gated(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
+                                          _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws),
+                                          B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_gated")
         if ctx.mod._kf_keep is not None:
             # d/dk of (mask * FFT(k)): mask the fp32 dk_f partial sums (same internal order as k_f) before the inverse
             nfl = H * plan.kf_elems * 2
@@ -236,8 +246,6 @@ class _FlashFFTConvFn(torch.autograd.Function):
         dk = dk.to(ctx.k_dtype)
         if not ctx.gated:
             return du, dk, None, None, None
-        # dpostgate = dout * conv(u*pregate, k): recompute the forward with dout as the output gate
-        dpost = _conv(plan, u, kf, pregate, dout, False)
         return du, dk, None, dpre, dpost
 
 
@@ -257,6 +265,16 @@ class FlashFFTConv(torch.nn.Module):
         self._plans = {}
         self._kf_keep = None        # frequency-sparse mode: keep bins |f| < _kf_keep (set by sparse_conv)
         self._masks = {}
+        # Opt-in inference cache of k_f (the reference recomputes FFT(k) in every forward,
+        # conv.py:572-575; its users hand-roll kernel caching, examples/bert/README.md).  When True and `k` does not
+        # require grad, k_f is reused while k is the same storage at the same version.  Off by default: a filter
+        # that is re-generated into recycled memory every step would look "unchanged".
+        self.cache_kf = False
+        self._kf_cache = None
+
+    def _cached_kf(self, k):
+        c = self._kf_cache
+        return c[1] if c is not None and c[0] == _kf_key(k) else None
 
     def _kf_mask(self, plan, dtype):
         """0/1 mask over k_f's internal positions keeping the natural frequencies |f| < self._kf_keep."""

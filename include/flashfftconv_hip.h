@@ -59,6 +59,12 @@ int ffc_conv_bwd_dkf(const ffc_plan* plan, const void* dout, const void* u, cons
  * transforms per pair like the reference's bwd kernels, dk_f kept in fp32. */
 int ffc_conv_bwd(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
                  const void* postgate, void* du, void* dpre, void* ws, int64_t B, int64_t H, int64_t L, void* stream);
+/* Same plus dpost = dout * conv(u*pregate, k) (nullable): the gated backward of GatedFlashFFTConvFunc
+ * (conv.py:3236-4958) in one call.  For fft sizes >= 4096 dpost comes out of the same launch (the forward output is one
+ * extra inverse transform of the first spectrum of each pair); the reference recomputes the forward for it too. */
+int ffc_conv_bwd_gated(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
+                       const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H, int64_t L,
+                       void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

@@ -163,9 +163,11 @@ def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchun
     ws = np.full(max(nchunk, 1) * upw * H * nt * 2048, np.nan, np.float32)
     du = np.zeros_like(u_bits)
     dpre = np.zeros_like(u_bits) if pre is not None else None
-    nslab = lib().ffcsim_conv_bwd(N, dtype, p(dout_bits), p(u_bits), p(kf_bits), p(pre), p(post), p(du), p(dpre), p(ws),
-                                  B, H, L, nchunk)
+    dpost = np.zeros_like(u_bits) if pre is not None else None
+    nslab = lib().ffcsim_conv_bwd(N, dtype, p(dout_bits), p(u_bits), p(kf_bits), p(pre), p(post), p(du), p(dpre), p(dpost),
+                                  p(ws), B, H, L, nchunk)
     assert nslab > 0, nslab
     dk = np.full((H, Lk), np.nan, np.float32)
     assert lib().ffcsim_kernel_ifft_grad(N, dtype, p(ws), nslab, H, Lk, p(dk)) == 0
+    sim_bwd.dpost = dpost          # fused sizes >= 4096 only (N <= 1024 leaves zeros: the library runs the forward kernel)
     return du, dpre, dk

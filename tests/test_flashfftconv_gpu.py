@@ -269,3 +269,25 @@ def test_sparse_conv_golden(path):
     assert rel(out, t("out", torch.float32)) < tol
     assert rel(x.grad, t("dx", torch.float32)) < tol
     assert rel(k.grad, t("dk", torch.float32)) < max(tol, 1e-2)
+
+
+def test_kf_cache_opt_in():
+    """cache_kf: k_f is reused only while k is the same storage at the same version and needs no grad."""
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(3)
+    conv = FlashFFTConv(4096, dtype=torch.bfloat16).to("cuda").eval()
+    u = torch.randn(2, 8, 2048, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(8, 2048, device="cuda") * 0.1
+    y0 = conv(u, k)
+    conv.cache_kf = True
+    y1 = conv(u, k); kf1 = conv._kf_cache[1]
+    y2 = conv(u, k)
+    assert conv._kf_cache[1] is kf1 and torch.equal(y0, y1) and torch.equal(y1, y2)
+    k.mul_(2.0)                                   # in-place update bumps the version -> recomputed
+    y3 = conv(u, k)
+    assert conv._kf_cache[1] is not kf1
+    assert rel(y3, ref_fft_conv(u, k, n=4096)) < 2e-2
+    kg = k.clone().requires_grad_(True)           # a trainable filter never uses the cache
+    conv.train()
+    conv(u, kg).sum().backward()
+    assert kg.grad is not None
