@@ -6,9 +6,19 @@ using namespace ffc;
 // register file (128 VGPRs at 2 waves per SIMD) is what the allocator gets.
 template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void dkf_kernel(DkfArgs d) {
-  int h, chunk;
-  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevBO, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
+  if constexpr (GEO::NW == 1) {
+    // one wave per unit (fft 4096): persistent workgroups walk the (head, chunk) jobs (see conv_kernel); the waves
+    // only meet at the table copy and at the end-of-chunk reduction of the dk_f sums
+    const int total = ((d.c.H + 7) & ~7) * d.c.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) Modes<DevBO, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
+    }
+  } else {
+    int h, chunk;
+    if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+    Modes<DevBO, GEO, DT>::template dkf<HALF>(d, h, chunk, blockIdx.x);
+  }
 }
 template <class GEO, int DT>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel_small(DkfArgs d) {   // single-tile sizes (N <= 1024)
@@ -20,7 +30,9 @@ template <class GEO, int DT>
 struct DkfLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
-    const dim3 grid(hpad * d.c.nchunk), block(GEO::WGW * 64);
+    int ngrid = hpad * d.c.nchunk;
+    if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
+    const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
       static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES);
       if (rc) return rc;
@@ -47,9 +59,19 @@ struct DkfLaunch {
 
 template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_kernel(DkfArgs d) {
-  int h, chunk;
-  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+  if constexpr (GEO::NW == 1) {
+    // one wave per unit (fft 4096): persistent workgroups walk the (head, chunk) jobs (see conv_kernel); the waves
+    // only meet at the table copy and at the end-of-chunk reduction of the dk_f sums
+    const int total = ((d.c.H + 7) & ~7) * d.c.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+    }
+  } else {
+    int h, chunk;
+    if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+    Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+  }
 }
 template <class GEO, int DT>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel_small(DkfArgs d) {
@@ -61,7 +83,9 @@ template <class GEO, int DT>
 struct BwdLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
-    const dim3 grid(hpad * d.c.nchunk), block(GEO::WGW * 64);
+    int ngrid = hpad * d.c.nchunk;
+    if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
+    const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
       static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES);
       if (rc) return rc;
@@ -120,6 +144,8 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  a.persist = p->num_cu & ~7;
+  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
   d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
 }
@@ -151,6 +177,8 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  a.persist = p->num_cu & ~7;
+  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   d.dpost = p->hp.N1 > 1 ? dpost : nullptr;
   if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;
