@@ -87,8 +87,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if int(os.environ.get("FFC_BENCH_SAME_GPU", "0")):     # test hook: all ranks on cuda:0
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl" on ROCm) over xGMI; FFC_BENCH_BACKEND=gloo only exists to exercise this path on a 1-GPU box
+        dist.init_process_group(os.environ.get("FFC_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local if world > 1 else 0)
     torch.cuda.set_device(dev)
 
