@@ -155,19 +155,30 @@ def main():
     seq_s = world * rows / sec_per_step
     dense_fwd = flops_dense_fwd_per_row(N)
     fft_fwd, fft_bwd = flops_fft_equiv(N)
-    # roofline for the dominant kernel of the forward direction: conv_kernel (one launch = all rows)
-    t_conv = kt["conv_fwd"]
-    alg_flops = dense_fwd * rows                       # 42.9 MFLOP/row x 12288 rows
-    alg_bytes = B * H * L * 2 * 2 + H * N * 4          # read u, write y, read k_f once
-    roof = {"kernel": "conv_kernel<Geo<32,32,32>,bf16> (forward)", "bound": "mfma",
-            "achieved": alg_flops / t_conv / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": alg_flops / t_conv / 1e12 / MFMA_PEAK_TFLOPS,
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-            # profiles/r01_end_pmc_conv_kernel.txt; not re-measured inside bench.py
-            "traffic": 1611.6e6, "traffic_source": "profiles/r01_end_pmc_conv_kernel.txt",
-            "launch_ms": t_conv * 1e3,
-            "hbm_GBs": alg_bytes / t_conv / 1e9, "hbm_frac": alg_bytes / t_conv / 1e9 / HBM_PEAK_GBS,
-            "basis": "SURVEY 8(d): dense Monarch 42.9 MFLOP/row (reference 32x32x32 factorisation) x rows; our pair-packed kernel executes ~half of these"}
+    # roofline objects: `roofline` = the dominant kernel of the step (bwd_kernel, ~60 % of the step time),
+    # `roofline_fwd` = the forward conv_kernel.  Flop basis = SURVEY 8(d): dense Monarch count of the reference's 32x32x32
+    # factorisation (forward 42.9 MFLOP/row; backward = 1.5 x the forward matmul flops + 14 N pointwise = 63.4 MFLOP/row),
+    # x rows per launch; our pair-packed kernels execute about half of these.
+    matmul_fwd = dense_fwd - 30 * N
+    dense_bwd = 1.5 * matmul_fwd + 14 * N
+    t_conv, t_bwd = kt["conv_fwd"], kt["bwd_fused"]
+    fwd_bytes = B * H * L * 2 * 2 + H * N * 4                      # read u, write y, read k_f once
+    bwd_bytes = B * H * L * 2 * 3 + H * N * 4 + H * N * 8          # read u + dout, write du, read k_f, write fp32 dk_f
+
+    def roof(name, flops_row, alg_bytes, t, traffic, src):
+        fl = flops_row * rows
+        return {"kernel": name, "bound": "mfma", "achieved": fl / t / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / t / 1e12 / MFMA_PEAK_TFLOPS,
+                # L2<->fabric bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
+                # measured by tests/measure_r01_end.sh / tests/pmc_bwd.sh, not re-measured inside bench.py
+                "traffic": traffic, "traffic_source": src, "launch_ms": t * 1e3,
+                "alg_bytes": alg_bytes, "hbm_GBs": alg_bytes / t / 1e9, "hbm_frac": alg_bytes / t / 1e9 / HBM_PEAK_GBS}
+
+    roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> (fused backward: du + fp32 dk_f)", dense_bwd, bwd_bytes, t_bwd,
+                    3826.4e6, "profiles/r01_end_pmc_bwd_kernel.txt")
+    roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF> (forward)", dense_fwd, fwd_bytes, t_conv,
+                    1611.7e6, "profiles/r01_end_pmc_conv_kernel.txt")
+    roof_bwd["basis"] = roof_fwd["basis"] = "SURVEY 8(d) dense-Monarch flops of the reference factorisation x rows per launch"
     out = {
         "metric": "FFT-conv fwd+bwd seq/s, B=16 H=768 L=16384 fft=32768 bf16",
         "value": seq_s, "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,7 +189,8 @@ def main():
         "tflops_dense_monarch": world * rows * dense_fwd * 2.5 / sec_per_step / 1e12,
         "tflops_fft_equiv": world * rows * (fft_fwd + fft_bwd) / sec_per_step / 1e12,
         "kernel_ms": {n: v * 1e3 for n, v in kt.items()},
-        "roofline": roof,
+        "roofline": roof_bwd,
+        "roofline_fwd": roof_fwd,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -19,6 +19,10 @@
 #include "ffc_layout.h"
 #include "ffc_plan.h"
 
+// activation rows go through non-temporal (streaming) global accesses: see DevB::g_r128_nt
+#ifndef FFC_STREAM_ROWS
+#define FFC_STREAM_ROWS 1
+#endif
 #ifndef FFC_FN
 #define FFC_FN inline __attribute__((always_inline))
 #endif
@@ -261,6 +265,10 @@ struct Body {
   // slice (the columns it transforms in phases A/C, so no barrier is needed around the copies).
   // Inner-only sizes: row g = pair q*G+g, the single wave of the unit moves the whole tile.
   // 16-byte global accesses, 1 KiB contiguous per wave instruction when L % 8 == 0.
+  // Measured (A/B on one box, B16 H768): forward 32K 0.513 -> 0.490 ms, 16K 0.298 -> 0.284; backward 16K 0.603 -> 0.579,
+  // 8K 0.268 -> 0.259, but backward 32K 0.988 -> 1.005 (its 128 KiB-per-workgroup spectrum scratch plus k_f already
+  // exceed the XCD's L2, so there is nothing left to protect): the 32K backward kernels keep plain accesses.
+  static constexpr bool STREAM_ROWS = FFC_STREAM_ROWS && !(B::LEAN_OUTER && GEO::N == 32768);
   struct RowIO {
     const uint16_t* src[2]; const uint16_t* gate[2]; uint16_t* dst[2]; bool valid[2];
   };
@@ -269,7 +277,7 @@ struct Body {
   // zero-initialised destination: consecutive loads never wait for each other, and the loads of the next pair
   // can stay in flight across phase C.
   static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, bool fast, bool rowok) {
-    if (fast) return B::g_r128(base, B::imin(n, L - 8) >> 3);
+    if (fast) return STREAM_ROWS ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
     u32 w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -281,7 +289,11 @@ struct Body {
     return v;
   }
   static FFC_FN void gstore8(uint16_t* base, i32 n, int L, bool fast, bool rowok, U4 v) {
-    if (fast) { B::g_w128(base, n >> 3, v, (n < L) && rowok); return; }
+    if (fast) {
+      if (STREAM_ROWS) B::g_w128_nt(base, n >> 3, v, (n < L) && rowok);
+      else B::g_w128(base, n >> 3, v, (n < L) && rowok);
+      return;
+    }
     u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; q++) {

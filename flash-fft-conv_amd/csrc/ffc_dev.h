@@ -171,6 +171,15 @@ struct DevB {
     uint4 v = ((const uint4*)base)[o16];
     return U4{v.x, v.y, v.z, v.w};
   }
+  // streaming variants (activation rows: read once / written once): non-temporal accesses do not displace the
+  // lines that ARE re-used (k_f[h] across a head's pairs, the spectrum scratch of the backward) from L2
+  static FFC_FN U4 g_r128_nt(const void* base, i32 o16) {
+    u32x4v v = __builtin_nontemporal_load(((const u32x4v*)base) + o16);
+    return U4{v.x, v.y, v.z, v.w};
+  }
+  static FFC_FN void g_w128_nt(void* base, i32 o16, U4 v, pred p) {
+    if (p) { u32x4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, ((u32x4v*)base) + o16); }
+  }
   static FFC_FN U4 g_r128p(const void* base, i32 o16, pred p) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (p) v = ((const uint4*)base)[o16];

@@ -229,6 +229,7 @@ struct SimB {
     }
     return r;
   }
+  static U4 g_r128_nt(const void* base, const i32& o16) { return g_r128(base, o16); }
   static U4 g_r128p(const void* base, const i32& o16, const pred& p) {
     U4 r;
     for (int i = 0; i < 64; i++) {
@@ -246,6 +247,7 @@ struct SimB {
         memcpy(q, &v.x.v[i], 4); memcpy(q + 4, &v.y.v[i], 4); memcpy(q + 8, &v.z.v[i], 4); memcpy(q + 12, &v.w.v[i], 4);
       }
   }
+  static void g_w128_nt(void* base, const i32& o16, const U4& v, const pred& p) { g_w128(base, o16, v, p); }
   // D[i][j] += sum_k A[i][k] B[k][j];  A lane l: A[l&31][8*(l>>5)+e];  B lane l: B[8*(l>>5)+e][l&31];
   // D lane l reg r: D[acc_row(r, l>>5)][l&31].
   template <int DT>
