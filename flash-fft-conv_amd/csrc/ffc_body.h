@@ -45,6 +45,7 @@ struct ConvArgs {
   float s_inv;           // 1/(N*s_fwd), applied with the outer inverse twiddle (fused sizes >= 4096)
   float s_fwd;           // forward scale, applied with the outer forward twiddle (fused sizes >= 4096)
   int flags;             // reserved tuning flags
+  int stream;            // 1: activation rows through non-temporal accesses (set by the host when every row is touched once)
   int persist;           // grid cap of the persistent one-wave-per-unit kernels (CU count rounded down to 8)
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
@@ -265,10 +266,11 @@ struct Body {
   // slice (the columns it transforms in phases A/C, so no barrier is needed around the copies).
   // Inner-only sizes: row g = pair q*G+g, the single wave of the unit moves the whole tile.
   // 16-byte global accesses, 1 KiB contiguous per wave instruction when L % 8 == 0.
-  // Measured (A/B on one box, B16 H768): forward 32K 0.513 -> 0.490 ms, 16K 0.298 -> 0.284; backward 16K 0.603 -> 0.579,
-  // 8K 0.268 -> 0.259, but backward 32K 0.988 -> 1.005 (its 128 KiB-per-workgroup spectrum scratch plus k_f already
-  // exceed the XCD's L2, so there is nothing left to protect): the 32K backward kernels keep plain accesses.
-  static constexpr bool STREAM_ROWS = FFC_STREAM_ROWS && !(B::LEAN_OUTER && GEO::N == 32768);
+  // Streaming rows (ConvArgs::stream, chosen by the host; FFC_STREAM=0/1 overrides it for A/B runs, tests/prof_stream.py).
+  // Same process, same box, B16 H768: forward 16K 0.323 -> 0.313 ms, gated forward 32K 0.442 -> 0.410; ungated backward
+  // 16K 0.667 -> 0.638, 32K 1.043 -> 1.025.  Not used in the gated backward, where the same workgroup reads u, dout and
+  // the gates a second time as output gates (cfg3: 0.839 -> 0.865 with streaming).
+  static constexpr bool STREAM_ROWS = FFC_STREAM_ROWS != 0;
   struct RowIO {
     const uint16_t* src[2]; const uint16_t* gate[2]; uint16_t* dst[2]; bool valid[2];
   };
@@ -276,8 +278,8 @@ struct Body {
   // missing batch rows are zeroed when the registers are written to E (rows_store).  No branch, no
   // zero-initialised destination: consecutive loads never wait for each other, and the loads of the next pair
   // can stay in flight across phase C.
-  static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, bool fast, bool rowok) {
-    if (fast) return STREAM_ROWS ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
+  static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, int fast, bool rowok) {
+    if (fast) return (STREAM_ROWS && fast == 2) ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
     u32 w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -288,9 +290,9 @@ struct Body {
     U4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
   }
-  static FFC_FN void gstore8(uint16_t* base, i32 n, int L, bool fast, bool rowok, U4 v) {
+  static FFC_FN void gstore8(uint16_t* base, i32 n, int L, int fast, bool rowok, U4 v) {
     if (fast) {
-      if (STREAM_ROWS) B::g_w128_nt(base, n >> 3, v, (n < L) && rowok);
+      if (STREAM_ROWS && fast == 2) B::g_w128_nt(base, n >> 3, v, (n < L) && rowok);
       else B::g_w128(base, n >> 3, v, (n < L) && rowok);
       return;
     }
@@ -319,7 +321,7 @@ struct Body {
   template <int NC>
   static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
-    const bool fast = a.fast;
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
     for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;
@@ -342,7 +344,7 @@ struct Body {
   template <int NC>
   static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
-    const bool fast = a.fast;
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
     for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;
@@ -385,7 +387,7 @@ struct Body {
   }
   // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
   // 32 bits in 16-byte units (launcher checks the tensor size).
-  static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, bool fast, pred ok) {
+  static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, int fast, pred ok) {
     if (fast) {
       i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
       return B::g_r128p(base, o16, ok && (n < a.L));
@@ -401,7 +403,7 @@ struct Body {
     U4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
   }
-  static FFC_FN void gstore8_rows(uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, bool fast, pred ok, U4 v) {
+  static FFC_FN void gstore8_rows(uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, int fast, pred ok, U4 v) {
     if (fast) {
       i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
       B::g_w128(base, o16, v, ok && (n < a.L));
@@ -419,7 +421,7 @@ struct Body {
   template <int NC = NCH>
   static FFC_FN void rows_out(const ConvArgs& a, int h, int pq, Unit un) {
     const i32 lane = B::opaque(B::lane());
-    const bool fast = a.fast;
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
     for (int i = 0; i < NC; i++) {
       i32 idx = lane + i * 64;

@@ -62,6 +62,8 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   a.persist = p->num_cu & ~7;
+  a.stream = 1;                       // every row is read / written exactly once per launch
+  if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
   if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;   // tuning knob
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }
