@@ -802,6 +802,11 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
+    if (a.flags & 2) {      // tuning flag: k_f as a streaming (non-temporal) read
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128_nt(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+      return;
+    }
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
   }

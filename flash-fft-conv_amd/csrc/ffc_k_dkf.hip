@@ -147,6 +147,7 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   a.persist = p->num_cu & ~7;
   a.stream = (!pregate && !postgate) ? 1 : 0;    // see Body::STREAM_ROWS
   if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
+  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
   d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
@@ -182,6 +183,7 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
   a.persist = p->num_cu & ~7;
   a.stream = (!pregate && !postgate) ? 1 : 0;    // see Body::STREAM_ROWS
   if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
+  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   d.dpost = p->hp.N1 > 1 ? dpost : nullptr;

@@ -197,7 +197,7 @@ struct Modes : Body<B, GEO, DT> {
       z.i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
     }
   }
-  static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im) {
+  static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im, bool nt = false) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -205,12 +205,18 @@ struct Modes : Body<B, GEO, DT> {
       U4 v;
       v.x = B::template pack<DT>(re[4 * rq], im[4 * rq]);         v.y = B::template pack<DT>(re[4 * rq + 1], im[4 * rq + 1]);
       v.z = B::template pack<DT>(re[4 * rq + 2], im[4 * rq + 2]); v.w = B::template pack<DT>(re[4 * rq + 3], im[4 * rq + 3]);
-      B::g_w128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
+      if (nt) B::g_w128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
+      else B::g_w128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
     }
   }
-  static FFC_FN void z_load(const void* zs, int tau, typename BD::KfRegs& z) {
+  static FFC_FN void z_load(const void* zs, int tau, typename BD::KfRegs& z, bool nt = false) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
+    if (nt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+      return;
+    }
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
   }
@@ -459,7 +465,7 @@ struct Modes : Body<B, GEO, DT> {
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
       typename BD::KfRegs zv;
-      z_load(zs, tau, zv);
+      z_load(zs, tau, zv, (a.flags & 4) != 0);
       typename BD::KfRegs kf;
       if constexpr (WITH_DX) BD::load_kf(a, h, tau, kf);
       A16 re, im;
@@ -522,7 +528,7 @@ struct Modes : Body<B, GEO, DT> {
           for (int tt = 0; tt < GEO::TPW; tt++) {
             A16 re, im;
             BD::template tile_fwd<false>(un.wq * GEO::TPW + tt, R, un, re, im);
-            z_store(zs, un.wq * GEO::TPW + tt, re, im);
+            z_store(zs, un.wq * GEO::TPW + tt, re, im, (a.flags & 4) != 0);
           }
         }
         BD::unit_barrier();
@@ -654,7 +660,7 @@ struct Modes : Body<B, GEO, DT> {
             const int tau = un.wq * GEO::TPW + tt;
             A16 re, im;
             BD::template tile_fwd<false>(tau, R, un, re, im);
-            z_store(zs, tau, re, im);
+            z_store(zs, tau, re, im, (a.flags & 4) != 0);
             if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
               // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
               typename BD::KfRegs kf;
