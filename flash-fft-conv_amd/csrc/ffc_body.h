@@ -329,6 +329,9 @@ struct Body {
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
         if constexpr (GEO::OUTER) {
+          // every lane of this chunk is beyond L (wave-uniform: the chunk's first row is a compile-time constant):
+          // nothing to fetch, rows_store writes zeros (L <= N/2 on the 16-point-digit sizes skips half the loads)
+          if (fast && ((i * 64) / CPR) * GEO::Mi >= a.L) { X.v[i][pl] = U4{B::uconst(0), B::uconst(0), B::uconst(0), B::uconst(0)}; continue; }
           const int b = 2 * pq + pl;
           const bool ok = b < a.B;
           const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
@@ -359,7 +362,7 @@ struct Body {
           v.x = B::sel(ok, v.x, B::uconst(0)); v.y = B::sel(ok, v.y, B::uconst(0));
           v.z = B::sel(ok, v.z, B::uconst(0)); v.w = B::sel(ok, v.w, B::uconst(0));
         }
-        if (a.pregate) {
+        if (a.pregate && !(GEO::OUTER && fast && ((i * 64) / CPR) * GEO::Mi >= a.L)) {
           U4 g;
           if constexpr (GEO::OUTER) {
             const int b = 2 * pq + pl;
