@@ -288,19 +288,40 @@ static int ffc_dispatch(int N, int dtype, A&&... args) {
 // (Modes::w_acc_finish) and write one slab; the single-tile geometries (N <= 1024) write one per unit.
 static inline int ffc_slabs_per_chunk(const ffc_plan* p) { return p->hp.N1 > 1 ? 1 : 8 / p->hp.NW; }
 
-static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* nchunk, int* ppc) {
+static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* nchunk, int* ppc, bool fwd_only = false) {
   const bool outer = p->hp.N1 > 1;
   int upw = 8 / p->hp.NW;                       // units a workgroup processes per iteration
   int pairs_per_iter = outer ? upw : upw * p->hp.G;
   int wg_per_cu = outer ? 1 : 2;
-  int mult = 2;   // see profiles/: larger values did not help (k_f re-reads are not the limiter)
-  if (const char* e = getenv("FFC_WG_MULT")) mult = atoi(e) > 0 ? atoi(e) : 2;   // tuning knob
-  int target = p->num_cu * wg_per_cu * mult;
   int iters_total = (npair + pairs_per_iter - 1) / pairs_per_iter;
-  int nc = (target + H - 1) / H;
-  if (nc > iters_total) nc = iters_total;
-  if (nc < 1) nc = 1;
-  int ipc = (iters_total + nc - 1) / nc;
+  int ipc;
+  const char* e = getenv("FFC_WG_MULT");         // tuning knob of the workgroups-per-slot rule
+  if (e || !fwd_only) {
+    // backward family (the kernel, its workspace and dkifft must agree, and every extra chunk is one more fp32 dk_f
+    // slab per head): at least `mult` workgroups per slot.  Larger values did not help (profiles/, tests/prof_mult.py).
+    int mult = (e && atoi(e) > 0) ? atoi(e) : 2;
+    int target = p->num_cu * wg_per_cu * mult;
+    int nc = (target + H - 1) / H;
+    if (nc > iters_total) nc = iters_total;
+    if (nc < 1) nc = 1;
+    ipc = (iters_total + nc - 1) / nc;
+  } else {
+    // forward / input-gradient kernel (no per-chunk state): iterations per chunk that minimise
+    // (rounds of workgroups over the chip) x (iterations per workgroup + 0.6 for its start-up); ties go to the longer
+    // chunks (k_f[h] re-used by one workgroup).  With many heads every choice ties and a workgroup takes all pairs of
+    // its head (768 heads x 8 pairs: 3 even rounds); with few heads (a head-sharded rank: 96 or 192 heads x 8 pairs) the
+    // pairs are spread so that the last round is not half empty (tests/prof_heads.py, same process: forward 0.169 -> 0.146 ms
+    // at B = 16 H = 192, 0.168 -> 0.158 at B = 64 H = 48; unchanged at H = 96 / 384 / 768).
+    const long slots = (long)p->num_cu * wg_per_cu;
+    long best = -1;
+    ipc = iters_total;
+    for (int c = 1; c <= iters_total; c++) {
+      long nch = (iters_total + c - 1) / c;
+      long rounds = ((long)H * nch + slots - 1) / slots;
+      long cost = rounds * (10L * c + 6);
+      if (best < 0 || cost <= best) { best = cost; ipc = c; }
+    }
+  }
   *ppc = ipc * pairs_per_iter;
   *nchunk = (npair + *ppc - 1) / *ppc;
 }

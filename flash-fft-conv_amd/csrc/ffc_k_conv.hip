@@ -60,7 +60,7 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.flags = 0;
   if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
-  ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
+  ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = p->num_cu & ~7;
   a.stream = 1;                       // every row is read / written exactly once per launch
   if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
