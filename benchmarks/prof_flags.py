@@ -19,8 +19,8 @@ for (N, B, H, L) in ((32768, 16, 768, 16384), (16384, 16, 768, 8192)):
     ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda"); du = torch.empty_like(u)
     for rep in range(2):
         for fl in ("0", "2", "4", "6"):
-            os.environ["FFC_FLAGS"] = fl
+            os.environ["FFC_FLAGS"] = fl; __import__("flashfftconv.conv").conv.reload_env()
             tf = ev(lambda: C._conv(plan, u, kf, None, None, False))
             tb = ev(lambda: _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(du), None, _lib.ptr(ws), B, H, L, sp()), "bwd"))
             print(f"N={N} FFC_FLAGS={fl}: conv_fwd {tf:.4f}  bwd_fused {tb:.4f}", flush=True)
-    os.environ.pop("FFC_FLAGS")
+    os.environ.pop("FFC_FLAGS"); __import__("flashfftconv.conv").conv.reload_env()

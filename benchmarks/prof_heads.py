@@ -26,4 +26,4 @@ for (N, B, H, L) in ((32768, 16, 96, 16384), (32768, 16, 192, 16384), (32768, 16
             tf = ev(lambda: mod(u, k))
         tb = ev(bwd)
         print(f"fft={N} B={B} H={H} L={L} {'cost-based chunks' if mode is None else 'former rule (mult 2)'}: fwd {tf:.4f} bwd {tb:.4f}", flush=True)
-    os.environ.pop("FFC_WG_MULT", None)
+    os.environ.pop("FFC_WG_MULT", None); __import__("flashfftconv.conv").conv.reload_env()

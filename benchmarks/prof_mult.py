@@ -17,7 +17,7 @@ for (N, B, H, L) in ((32768, 16, 768, 16384), (16384, 8, 1024, 8192), (16384, 16
     mod = FlashFFTConv(N, dtype=torch.bfloat16).cuda(); plan = mod._get_plan(u.device)
     kf = C._kernel_fft(plan, k); du = torch.empty_like(u); dk = torch.empty(H, L, device="cuda")
     for mult in ("1", "2", "3", "4", "8"):
-        os.environ["FFC_WG_MULT"] = mult
+        os.environ["FFC_WG_MULT"] = mult; __import__("flashfftconv.conv").conv.reload_env()
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda")
         tf = ev(lambda: C._conv(plan, u, kf, None, None, False))
         def bw():
@@ -25,4 +25,4 @@ for (N, B, H, L) in ((32768, 16, 768, 16384), (16384, 8, 1024, 8192), (16384, 16
             _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, L, _lib.ptr(dk), sp()), "dk")
         tb = ev(bw)
         print(f"N={N} B={B} H={H} L={L} FFC_WG_MULT={mult}: conv_fwd {tf:.4f}  bwd+dkifft {tb:.4f}  ws {ws.numel()/1e6:.0f} MB", flush=True)
-    os.environ.pop("FFC_WG_MULT")
+    os.environ.pop("FFC_WG_MULT"); __import__("flashfftconv.conv").conv.reload_env()

@@ -16,10 +16,10 @@ for (N, B, H, L) in ((4096, 16, 768, 2048), (4096, 16, 768, 4096), (4096, 16, 12
     mod = FlashFFTConv(N, dtype=torch.bfloat16).cuda(); plan = mod._get_plan(u.device)
     kf = C._kernel_fft(plan, k)
     for persist in ("0", "256", "512", "128"):
-        os.environ["FFC_PERSIST"] = persist
+        os.environ["FFC_PERSIST"] = persist; __import__("flashfftconv.conv").conv.reload_env()
         t = ev(lambda: C._conv(plan, u, kf, None, None, False))
         print(f"N={N} B={B} H={H} L={L} FFC_PERSIST={persist}: conv fwd {t:.4f} ms", flush=True)
-    os.environ.pop("FFC_PERSIST")
+    os.environ.pop("FFC_PERSIST"); __import__("flashfftconv.conv").conv.reload_env()
 from flashfftconv import _lib
 lib = _lib.lib(); sp = _lib.stream_ptr
 for (N, B, H, L) in ((4096, 16, 768, 2048), (8192, 16, 768, 4096), (16384, 16, 768, 8192)):

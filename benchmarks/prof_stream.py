@@ -28,4 +28,4 @@ for (N, B, H, L, gated) in ((16384, 8, 1024, 8192, True), (16384, 16, 768, 8192,
                 tf = ev(lambda: mod(u, k, *g))
             tb = ev(bwd)
             print(f"N={N} B={B} H={H} L={L} gated={gated} FFC_STREAM={mode}: fwd {tf:.4f} bwd {tb:.4f}", flush=True)
-    os.environ.pop("FFC_STREAM", None)
+    os.environ.pop("FFC_STREAM", None); __import__("flashfftconv.conv").conv.reload_env()

@@ -1,4 +1,4 @@
-"""Copies the judged summaries of gpurun_out/r01_end (tests/measure_r01_end.sh) into profiles/r01_end_*."""
+"""Copies the judged summaries of gpurun_out/r01_end (benchmarks/measure_r01_end.sh) into profiles/r01_end_*."""
 import csv, collections, os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(ROOT, "gpurun_out", "r01_end"), os.path.join(ROOT, "profiles")
@@ -17,8 +17,8 @@ for d in ("p1", "p2", "p3", "p4"):
         out[k] = sum(v) / len(v)
 with open(f"{P}/r01_end_pmc_conv_kernel.txt", "w") as f:
     w = lambda s: f.write(s + "\n")
-    w("# rocprofv3 --pmc (separate passes per counter group, no tracing domains besides --kernel-trace; tests/measure_r01_end.sh),")
-    w("# tests/prof_conv.py: conv_kernel<Geo<32,32,32>,bf16,HALF> forward, config 2 (B16 H768 L16384), per dispatch (avg of 4)")
+    w("# rocprofv3 --pmc (separate passes per counter group, no tracing domains besides --kernel-trace; benchmarks/measure_r01_end.sh),")
+    w("# benchmarks/prof_conv.py: conv_kernel<Geo<32,32,32>,bf16,HALF> forward, config 2 (B16 H768 L16384), per dispatch (avg of 4)")
     for k, v in out.items():
         w(f"{k:28s}{v:.4e}")
     fs, ws, wc = out["FETCH_SIZE"], out["WRITE_SIZE"], out["SQ_WAVE_CYCLES"]

@@ -50,12 +50,13 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
     fft_f, fft_b = 2 * 5 * N * lg + 6 * N, 3 * 5 * N * lg + 14 * N
     alg_f = B * H * L * 2 * (2 + 2 * gated) + H * N * 4
     alg_b = B * H * L * 2 * (3 + 4 * gated) + H * N * 4 + H * N * 8
-    print(json.dumps({"row": name, "fft": N, "B": B, "H": H, "L": L, "dtype": str(dtype).split(".")[-1], "gated": gated,
+    return ({"row": name, "fft": N, "B": B, "H": H, "L": L, "dtype": str(dtype).split(".")[-1], "gated": gated,
                       "H_run": Hrun, "rescaled": Hrun != H,
                       "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4), "fwd_bwd_ms": round(t_f + t_b, 4),
                       "seq_per_s": round(rows / ((t_f + t_b) * 1e-3)),
                       "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
-                      "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9)}), flush=True)
+                      "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9),
+                      "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4)})
 
 
 def conv1d_row():
@@ -75,20 +76,34 @@ def conv1d_row():
         y.backward(dout, retain_graph=True)
     t_b = ev_time(bwd, 5)
     byts = B * L * D * 2 * 2 + K * D * 2
-    print(json.dumps({"row": "cfg5 conv1d k=3 B=64 H=2048 L=8192 bf16 BHL", "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
-                      "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9), "bwd_GBs": round(1.5 * byts / (t_b * 1e-3) / 1e9)}), flush=True)
+    return ({"row": "cfg5 conv1d k=3 B=64 H=2048 L=8192 bf16 BHL", "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
+                      "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9), "bwd_GBs": round(1.5 * byts / (t_b * 1e-3) / 1e9),
+                      "fwd_hbm_frac": round(byts / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(1.5 * byts / (t_b * 1e-3) / 8e12, 4)})
+
+
+def config_rows():
+    yield conv_row("cfg2 FlashFFTConv(32768) B16 H768 L16384", 32768, 16, 768, 16384)
+    yield conv_row("cfg3 gated fft16384 B8 H1024 L8192", 16384, 8, 1024, 8192, gated=True)
+    yield conv_row("cfg4 FlashFFTConv(4194304) B1 H16 L1048576", 4194304, 1, 16, 1048576)
+    yield conv1d_row()
+
+
+def sweep_rows(lg_lo=10, lg_hi=20):
+    """BASELINE metric: B=16, H=768, L = 1K .. 1M, fft size 2L (heads reduced and rescaled above fft 128K, as the
+    reference's own benchmark does)"""
+    for lg in range(lg_lo, lg_hi + 1):
+        L = 1 << lg
+        N = 2 * L
+        Hrun = 768 if N <= 131072 else max(16, 768 * 131072 // N)
+        yield conv_row(f"sweep L={L}", N, 16, 768, L, Hrun=Hrun)
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "configs"):
-        conv_row("cfg2 FlashFFTConv(32768) B16 H768 L16384", 32768, 16, 768, 16384)
-        conv_row("cfg3 gated fft16384 B8 H1024 L8192", 16384, 8, 1024, 8192, gated=True)
-        conv_row("cfg4 FlashFFTConv(4194304) B1 H16 L1048576", 4194304, 1, 16, 1048576)
-        conv1d_row()
+        for r in config_rows():
+            print(json.dumps(r), flush=True)
     if which in ("all", "sweep"):
-        for lg in range(10, 21):
-            L = 1 << lg
-            N = 2 * L
-            Hrun = 768 if N <= 131072 else max(16, 768 * 131072 // N)
-            conv_row(f"sweep L={L}", N, 16, 768, L, Hrun=Hrun)
+        for r in sweep_rows():
+            print(json.dumps(r), flush=True)

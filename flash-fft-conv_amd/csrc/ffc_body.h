@@ -266,7 +266,7 @@ struct Body {
   // slice (the columns it transforms in phases A/C, so no barrier is needed around the copies).
   // Inner-only sizes: row g = pair q*G+g, the single wave of the unit moves the whole tile.
   // 16-byte global accesses, 1 KiB contiguous per wave instruction when L % 8 == 0.
-  // Streaming rows (ConvArgs::stream, chosen by the host; FFC_STREAM=0/1 overrides it for A/B runs, tests/prof_stream.py).
+  // Streaming rows (ConvArgs::stream, chosen by the host; FFC_STREAM=0/1 overrides it for A/B runs, benchmarks/prof_stream.py).
   // Same process, same box, B16 H768: forward 16K 0.323 -> 0.313 ms, gated forward 32K 0.442 -> 0.410; ungated backward
   // 16K 0.667 -> 0.638, 32K 1.043 -> 1.025.  Not used in the gated backward, where the same workgroup reads u, dout and
   // the gates a second time as output gates (cfg3: 0.839 -> 0.865 with streaming).

@@ -435,7 +435,10 @@ int launch_fwd(const void* u, const void* w, const void* bias, void* y, int64_t 
   using SW = typename El<TW>::S;
   const int esz = sizeof(SI);
   if (bhl) {
-    bool fast = (Lin % V == 0) && (Lout % V == 0) && (K - 1 <= V) && !(((uintptr_t)u | (uintptr_t)y) & 15) && esz * V % 16 == 0;
+    // the fast path keeps inputs [l0 - V, l0 + 2V) in registers: tap index V + i + k - shift must stay inside [0, 3V)
+    const int shift = flip ? (K - 1 - P) : P;
+    bool fast = (Lin % V == 0) && (Lout % V == 0) && (K - 1 <= V) && shift >= 0 && shift <= V && (K - 1 - shift) <= V &&
+                !(((uintptr_t)u | (uintptr_t)y) & 15) && esz * V % 16 == 0;
     int64_t nblk = ((Lout + V * 256 - 1) / (V * 256)) * B * D;
     if (nblk > 2147483647LL) return fail1d("grid too large");
     dim3 block(256), grid((unsigned)nblk);

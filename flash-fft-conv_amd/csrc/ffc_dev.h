@@ -246,7 +246,16 @@ struct ffc_plan {
   uint8_t* d_blob_bf = nullptr;
   int32_t* d_freq = nullptr;
   int num_cu = 256;
+  // tuning knobs, read from the environment ONCE, at plan creation (not on every launch):
+  int env_flags = 0;        // FFC_FLAGS    : 2 = k_f streamed, 4 = spectrum scratch streamed (A/B runs)
+  int env_stream = -1;      // FFC_STREAM   : 0/1 overrides the streaming (non-temporal) row accesses, -1 = launcher's choice
+  int env_persist = -1;     // FFC_PERSIST  : grid cap of the persistent kernels (<= 0: uncapped), -1 = one workgroup per CU
+  int env_wg_mult = 0;      // FFC_WG_MULT  : workgroups-per-slot rule of the backward family, 0 = default (2)
 };
+static inline int ffc_persist(const ffc_plan* p) {
+  if (p->env_persist == -1) return p->num_cu & ~7;
+  return p->env_persist > 0 ? (p->env_persist & ~7) : 1 << 30;
+}
 
 extern "C" void ffc_set_error_(const char* m);
 static inline int ffc_fail(const std::string& m) { ffc_set_error_(m.c_str()); return 1; }
@@ -295,11 +304,11 @@ static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* n
   int wg_per_cu = outer ? 1 : 2;
   int iters_total = (npair + pairs_per_iter - 1) / pairs_per_iter;
   int ipc;
-  const char* e = getenv("FFC_WG_MULT");         // tuning knob of the workgroups-per-slot rule
-  if (e || !fwd_only) {
+  const int e = p->env_wg_mult;                  // tuning knob of the workgroups-per-slot rule (FFC_WG_MULT)
+  if (e > 0 || !fwd_only) {
     // backward family (the kernel, its workspace and dkifft must agree, and every extra chunk is one more fp32 dk_f
-    // slab per head): at least `mult` workgroups per slot.  Larger values did not help (profiles/, tests/prof_mult.py).
-    int mult = (e && atoi(e) > 0) ? atoi(e) : 2;
+    // slab per head): at least `mult` workgroups per slot.  Larger values did not help (profiles/, benchmarks/prof_mult.py).
+    int mult = e > 0 ? e : 2;
     int target = p->num_cu * wg_per_cu * mult;
     int nc = (target + H - 1) / H;
     if (nc > iters_total) nc = iters_total;
@@ -310,7 +319,7 @@ static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* n
     // (rounds of workgroups over the chip) x (iterations per workgroup + 0.6 for its start-up); ties go to the longer
     // chunks (k_f[h] re-used by one workgroup).  With many heads every choice ties and a workgroup takes all pairs of
     // its head (768 heads x 8 pairs: 3 even rounds); with few heads (a head-sharded rank: 96 or 192 heads x 8 pairs) the
-    // pairs are spread so that the last round is not half empty (tests/prof_heads.py, same process: forward 0.169 -> 0.146 ms
+    // pairs are spread so that the last round is not half empty (benchmarks/prof_heads.py, same process: forward 0.169 -> 0.146 ms
     // at B = 16 H = 192, 0.168 -> 0.158 at B = 64 H = 48; unchanged at H = 96 / 384 / 768).
     const long slots = (long)p->num_cu * wg_per_cu;
     long best = -1;

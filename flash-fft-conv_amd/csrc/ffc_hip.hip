@@ -63,6 +63,17 @@ void ffc_set_error_(const char* m) { g_err = m; }
 int ffc_version(void) { return 100; }
 const char* ffc_last_error(void) { return g_err.c_str(); }
 
+// (Re-)read the tuning knobs from the environment into the plan.  Called once by ffc_plan_create; A/B tuning scripts call
+// it again after changing a variable.  Launches never call getenv.
+void ffc_plan_reload_env(ffc_plan* p) {
+  if (!p) return;
+  p->env_flags = 0; p->env_stream = -1; p->env_persist = -1; p->env_wg_mult = 0;
+  if (const char* e = getenv("FFC_FLAGS")) p->env_flags = atoi(e);
+  if (const char* e = getenv("FFC_STREAM")) p->env_stream = atoi(e) ? 1 : 0;
+  if (const char* e = getenv("FFC_PERSIST")) p->env_persist = atoi(e) > 0 ? atoi(e) : 0;
+  if (const char* e = getenv("FFC_WG_MULT")) p->env_wg_mult = atoi(e);
+}
+
 int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
   if (!out) return fail("null out");
   ffc_plan* p = new ffc_plan();
@@ -90,6 +101,7 @@ int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) p->num_cu = prop.multiProcessorCount;
+  ffc_plan_reload_env(p);
   *out = p;
   return 0;
 }

@@ -57,14 +57,11 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.conj_kf = conj_kf;
   a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
-  a.flags = 0;
-  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
+  a.flags = p->env_flags;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
-  a.persist = p->num_cu & ~7;
-  a.stream = 1;                       // every row is read / written exactly once per launch
-  if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
-  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;   // tuning knob
+  a.persist = ffc_persist(p);
+  a.stream = p->env_stream >= 0 ? p->env_stream : 1;     // every row is read / written exactly once per launch
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }
 
@@ -96,8 +93,7 @@ extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* k
   a.u = u; a.y = y; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0);
-  a.flags = 0;
-  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
+  a.flags = p->env_flags;
   a.prof = prof;
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   static int rc = ffc_set_lds(conv_prof_kernel<GEO, DT_BF16>, GEO::LDS_BYTES);

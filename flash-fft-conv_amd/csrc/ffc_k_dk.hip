@@ -18,6 +18,24 @@ struct DkLaunch {
   }
 };
 
+// dk from `nslab` explicit fp32 slabs [nslab][H][kf_elems][2] (k_f's internal order): the entry point of callers that
+// reduce the partial sums themselves (B-shard multi-GPU: reduce-scatter over ranks, then one slab of H/W heads)
+extern "C" int ffc_kernel_ifft_grad_slabs(const ffc_plan* p, const void* slabs, int64_t nslab, int64_t H, int64_t Lk, float* dk,
+                                          void* stream) {
+  if (!p || !slabs || !dk) return ffc_fail("null arg");
+  if (H <= 0 || Lk <= 0 || Lk > p->hp.N) return ffc_fail("dk must be (H, Lk) with 0 < Lk <= fft_size");
+  if (nslab <= 0 || nslab > 65536) return ffc_fail("bad slab count");
+  if ((uintptr_t)slabs & 15) return ffc_fail("slabs must be 16-byte aligned");
+  DkArgs a{};
+  // always bf16 arithmetic: W/N underflows fp16 for small gradients, bf16 keeps fp32's range
+  a.ws = (const float*)slabs; a.dk = dk; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = (int)Lk;
+  a.nslab = (int)nslab;
+  a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
+  a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+  a.flags = p->env_flags;
+  return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
+}
+
 extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream) {
   if (!p || !ws || !dk) return ffc_fail("null arg");
   if (H <= 0 || Lk <= 0 || Lk > p->hp.N) return ffc_fail("dk must be (H, Lk) with 0 < Lk <= fft_size");
@@ -29,7 +47,7 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   a.nslab = nchunk * ffc_slabs_per_chunk(p);
   a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
-  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);
+  a.flags = p->env_flags;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }
 

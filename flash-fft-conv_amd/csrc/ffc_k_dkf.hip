@@ -144,11 +144,9 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
-  a.persist = p->num_cu & ~7;
-  a.stream = (!pregate && !postgate) ? 1 : 0;    // see Body::STREAM_ROWS
-  if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
-  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
-  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
+  a.persist = ffc_persist(p);
+  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate) ? 1 : 0);    // see Body::STREAM_ROWS
+  a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
 }
@@ -180,11 +178,9 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
-  a.persist = p->num_cu & ~7;
-  a.stream = (!pregate && !postgate) ? 1 : 0;    // see Body::STREAM_ROWS
-  if (const char* e = getenv("FFC_STREAM")) a.stream = atoi(e);      // tuning knob
-  if (const char* e = getenv("FFC_FLAGS")) a.flags = atoi(e);        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
-  if (const char* e = getenv("FFC_PERSIST")) a.persist = atoi(e) > 0 ? (atoi(e) & ~7) : 1 << 30;
+  a.persist = ffc_persist(p);
+  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate) ? 1 : 0);    // see Body::STREAM_ROWS
+  a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   d.dpost = p->hp.N1 > 1 ? dpost : nullptr;
   if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;

@@ -22,6 +22,7 @@ def lib():
         L.ffc_last_error.restype = ctypes.c_char_p
         L.ffc_plan_create.argtypes = [c_i64, c_int, ctypes.POINTER(c_vp)]
         L.ffc_plan_destroy.argtypes = [c_vp]
+        L.ffc_plan_reload_env.argtypes = [c_vp]; L.ffc_plan_reload_env.restype = None
         L.ffc_plan_kf_elems.argtypes = [c_vp]; L.ffc_plan_kf_elems.restype = c_i64
         L.ffc_plan_kf_scale.argtypes = [c_vp]; L.ffc_plan_kf_scale.restype = ctypes.c_double
         L.ffc_plan_kf_index.argtypes = [c_vp, c_vp]
@@ -34,6 +35,7 @@ def lib():
         L.ffc_conv_bwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
         L.ffc_conv_bwd_gated.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
         L.ffc_kernel_ifft_grad.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]
+        L.ffc_kernel_ifft_grad_slabs.argtypes = [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]
         c_f = ctypes.c_float
         L.ffc_outer_pass.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_vp]
         L.ffc_kernel_fft_c.argtypes = [c_vp, c_vp, c_i64, c_vp, c_f, c_vp]
@@ -56,6 +58,8 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """current stream of `device` (default: the current device; the autograd functions run under
+    torch.cuda.device(u.device), so that is the device of the tensors)"""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

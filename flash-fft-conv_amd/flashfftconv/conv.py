@@ -8,6 +8,8 @@ Semantics: y = iFFT(FFT(u, N) * FFT(k, N)).real[..., :L] with N = seqlen (refere
 tests/test_flashfftconv.py:5-13).  The reference's 4.9 KLoC `if seqlen == ...` dispatch
 (conv.py:563-4958) collapses to one table-driven plan inside the HIP library."""
 import ctypes
+import re
+import threading
 import torch
 
 from . import _lib
@@ -46,9 +48,41 @@ class _Plan:
     def __del__(self):
         try:
             if self.handle:
-                _lib.lib().ffc_plan_destroy(self.handle)
+                with torch.cuda.device(self.device):     # hipFree of the tables on the device that owns them
+                    _lib.lib().ffc_plan_destroy(self.handle)
         except Exception:
             pass
+
+
+# Plans are process-wide, keyed by (fft size, dtype, device index): modules hold no ctypes state, so they deep-copy and
+# pickle like the reference module (EMA / SWA copies, torch.save(model)); two modules of one size share the tables.
+_PLANS = {}
+_PLANS_LOCK = threading.Lock()
+
+
+def get_plan(seqlen, dtype, device):
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (seqlen, dtype, idx)
+    p = _PLANS.get(key)
+    if p is None:
+        with _PLANS_LOCK:
+            p = _PLANS.get(key)
+            if p is None:
+                p = _Plan(seqlen, dtype, torch.device("cuda", idx))
+                _PLANS[key] = p
+    return p
+
+
+def reload_env():
+    """tuning scripts: re-read FFC_* environment knobs into every cached plan (launches never read the environment)"""
+    for p in list(_PLANS.values()):
+        _lib.lib().ffc_plan_reload_env(p.handle)
+
+
+# Buffers the REFERENCE module registers (persistent, so they are in every checkpoint saved from it):
+# flashfftconv/conv.py:89-92, 106-109, ... (f_32_fft, f_sqrt_N_ifft, twiddle_factors_fft_32_1K, f_128_fft_real, twid, ...)
+_REF_BUFFER = re.compile(r"^(f_(\d+|sqrt_N)_i?fft(_real|_imag)?|twiddle_factors_i?fft(_\w+)?|twid)$")
 
 
 def _conv(plan, u, kf, pregate, postgate, conj):
@@ -163,6 +197,11 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len):
 def _check_inputs(mod, u, k, gates):
     if not u.is_cuda:
         raise RuntimeError("FlashFFTConv: u must be a CUDA/HIP tensor (no CPU fallback in the product path)")
+    if k.device != u.device:
+        raise RuntimeError(f"FlashFFTConv: k is on {k.device}, u on {u.device}")
+    for g in gates:
+        if g is not None and g.device != u.device:
+            raise RuntimeError(f"FlashFFTConv: gate is on {g.device}, u on {u.device}")
     if u.dim() != 3:
         raise RuntimeError("FlashFFTConv: u must be (B, H, L)")
     if u.dtype != mod.dtype:
@@ -183,6 +222,11 @@ class _FlashFFTConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, k, mod, pregate, postgate):
         _check_inputs(mod, u, k, (pregate, postgate))
+        with torch.cuda.device(u.device):      # launches go to u's device and its current stream
+            return _FlashFFTConvFn._forward(ctx, u, k, mod, pregate, postgate)
+
+    @staticmethod
+    def _forward(ctx, u, k, mod, pregate, postgate):
         u = u.contiguous()
         pregate = None if pregate is None else pregate.contiguous()
         postgate = None if postgate is None else postgate.contiguous()
@@ -211,6 +255,11 @@ class _FlashFFTConvFn(torch.autograd.Function):
     def backward(ctx, dout):
         if not ctx.saved_tensors:
             raise RuntimeError("FlashFFTConv: backward needs module.training=True at forward time")
+        with torch.cuda.device(ctx.saved_tensors[0].device):
+            return _FlashFFTConvFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         dout = dout.contiguous()
         if ctx.gated:
             u, kf, pregate, postgate = ctx.saved_tensors
@@ -250,7 +299,19 @@ class _FlashFFTConvFn(torch.autograd.Function):
 
 
 class FlashFFTConv(torch.nn.Module):
-    """reference: flashfftconv/conv.py:71-560."""
+    """reference: flashfftconv/conv.py:71-560.
+
+    Differences a caller can observe:
+      * `use_32_butterfly` is accepted for signature compatibility and has no effect: in the reference it only selects
+        which of two equivalent factorisations (16- or 32-point outer butterfly) an fft size >= 65536 uses
+        (conv.py:262-551); here the factorisation is internal to the plan (flashfftconv/bigfft.py) and the result is
+        the same convolution either way.
+      * no tables are registered as buffers: `state_dict()` of this module is empty.  Checkpoints saved from the
+        reference module carry its DFT / twiddle buffers (`*.f_32_fft`, `*.twiddle_factors_fft_32_1K`, ...); they are
+        accepted and discarded on load, so `load_state_dict(strict=True)` of a reference checkpoint works.
+      * one tensor must stay below 2^31 elements (B*H*L, and for fft sizes >= 65536 also 2*ceil(B/2)*H*fft_size, the
+        complex intermediate): larger calls raise RuntimeError; split the batch.
+      * H % 16 == 0 is NOT required for fft sizes > 32768 (reference README.md:269), L may be any length <= fft size."""
 
     def __init__(self, seqlen, dtype=torch.float16, use_32_butterfly=True):
         super().__init__()
@@ -261,8 +322,7 @@ class FlashFFTConv(torch.nn.Module):
         self._folded = seqlen in FOLDED_SEQLENS
         self._plan_seqlen = FOLDED_SEQLENS.get(seqlen, seqlen)
         self.dtype = dtype
-        self.use_32_butterfly = use_32_butterfly
-        self._plans = {}
+        self.use_32_butterfly = use_32_butterfly      # no effect, see the class docstring
         self._kf_keep = None        # frequency-sparse mode: keep bins |f| < _kf_keep (set by sparse_conv)
         self._masks = {}
         # Opt-in inference cache of k_f (the reference recomputes FFT(k) in every forward,
@@ -278,7 +338,7 @@ class FlashFFTConv(torch.nn.Module):
 
     def _kf_mask(self, plan, dtype):
         """0/1 mask over k_f's internal positions keeping the natural frequencies |f| < self._kf_keep."""
-        key = (id(plan), dtype, self._kf_keep)
+        key = (plan.seqlen, plan.device.index, dtype, self._kf_keep)
         m = self._masks.get(key)
         if m is None:
             import numpy as np
@@ -292,13 +352,14 @@ class FlashFFTConv(torch.nn.Module):
         return m
 
     def _get_plan(self, device, N=None):
-        N = self.seqlen if N is None else N
-        key = (N, device.type, device.index if device.index is not None else torch.cuda.current_device())
-        p = self._plans.get(key)
-        if p is None:
-            p = _Plan(N, self.dtype, device)
-            self._plans[key] = p
-        return p
+        return get_plan(self.seqlen if N is None else N, self.dtype, device)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        # swallow the reference module's table buffers (see _REF_BUFFER): a reference checkpoint loads strictly
+        for key in [k for k in state_dict if k.startswith(prefix) and "." not in k[len(prefix):]
+                    and _REF_BUFFER.match(k[len(prefix):])]:
+            del state_dict[key]
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
 
     def forward(self, u, k, pregate=None, postgate=None):
         if pregate is not None or postgate is not None:

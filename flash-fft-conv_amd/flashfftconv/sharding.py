@@ -1,8 +1,20 @@
-"""Multi-GPU execution of the FFT-conv path: every (b, h) row is independent given k[h], so the
-head axis shards across ranks with NO data-path collective: rank r owns heads
-[r*H/W, (r+1)*H/W) of u, k, the gates, y and dk.  One process per GPU, torch.distributed over
-RCCL/xGMI (backend "nccl") only for the optional gather of results / dk.
-The reference has no distributed code in its core; this is new, not a port."""
+"""Multi-GPU execution of the FFT-conv path.  One process per GPU, torch.distributed over
+RCCL/xGMI (backend "nccl"); every (b, h) row is independent given k[h], so there are two ways to split:
+
+  H-shard (HeadShardedFFTConv)   rank r owns heads [r*H/W, (r+1)*H/W) of u, k, the gates, y and dk.
+                                 NO data-path collective; optional all-gather of y for callers that need it replicated.
+  B-shard (BatchShardedFFTConv)  data parallel: rank r owns batch rows, k is replicated (a DDP-style parameter).
+                                 forward : every rank transforms H/W heads of k on the device and the ranks ALL-GATHER
+                                           k_f (cfg2: 100.7 MB total) instead of each recomputing all of FFT(k);
+                                 backward: each rank's fp32 dk_f partial sums (over ITS batch rows, all heads) are
+                                           REDUCE-SCATTERed, each rank inverts its H/W heads, dk is all-gathered so the
+                                           replicated parameter gets the full gradient (what DDP's all-reduce would give).
+                                 mode="recompute" skips the k_f exchange (every rank runs the whole FFT(k), dk is
+                                 all-reduced): cheaper than the collective's latency for short fft sizes, and the only mode
+                                 for fft sizes >= 65536.
+
+The compute goes through an `ops` object (GPU: _HipOps over the C-ABI; CPU tests: a torch.fft stand-in) so the collective
+logic is exercised by world_size-2 gloo tests without a GPU.  The reference has no distributed code; this is new."""
 import torch
 import torch.distributed as dist
 
@@ -21,11 +33,16 @@ def shard_heads(x, dim, rank=None, world=None):
     return x.narrow(dim, s, e - s).contiguous()
 
 
-def gather_heads(x_local, H, dim, group=None):
+def _all_gather_uneven(x_local, H, dim, group=None):
     """All-gather head shards back to the full tensor (uneven shards supported via padding)."""
     world = dist.get_world_size(group)
     sizes = [head_range(H, r, world)[1] - head_range(H, r, world)[0] for r in range(world)]
     m = max(sizes)
+    if all(s == m for s in sizes) and dim == 0 and x_local.is_contiguous():
+        out = x_local.new_empty((H,) + tuple(x_local.shape[1:]))
+        dist.all_gather_into_tensor(out, x_local, group=group) if dist.get_backend(group) == "nccl" else \
+            dist.all_gather(list(out.chunk(world, 0)), x_local, group=group)
+        return out
     pad_shape = list(x_local.shape); pad_shape[dim] = m
     buf = x_local.new_zeros(pad_shape)
     buf.narrow(dim, 0, x_local.shape[dim]).copy_(x_local)
@@ -34,18 +51,172 @@ def gather_heads(x_local, H, dim, group=None):
     return torch.cat([o.narrow(dim, 0, s) for o, s in zip(outs, sizes)], dim=dim)
 
 
+def _reduce_scatter_heads(x_full, dim, group=None):
+    """sum over ranks of x_full, this rank's head range of the result."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H = x_full.shape[dim]
+    s, e = head_range(H, rank, world)
+    if dist.get_backend(group) == "nccl" and H % world == 0 and dim == 0 and x_full.is_contiguous():
+        out = x_full.new_empty((H // world,) + tuple(x_full.shape[1:]))
+        dist.reduce_scatter_tensor(out, x_full, group=group)
+        return out
+    x = x_full.clone()
+    dist.all_reduce(x, group=group)          # gloo (CPU tests / same-GPU tests) and uneven shards
+    return x.narrow(dim, s, e - s).contiguous()
+
+
+class _GatherHeads(torch.autograd.Function):
+    """all-gather along `dim`, differentiable: every rank holds (and may use) the whole gathered tensor, so the gradient
+    of a rank's shard is the SUM over ranks of that shard's slice of their gradients (reduce-scatter)."""
+
+    @staticmethod
+    def forward(ctx, x_local, H, dim, group):
+        ctx.dim, ctx.group = dim, group
+        return _all_gather_uneven(x_local.contiguous(), H, dim, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _reduce_scatter_heads(g.contiguous(), ctx.dim, ctx.group), None, None, None
+
+
+def gather_heads(x_local, H, dim, group=None):
+    """Differentiable all-gather of head shards (round 1 used dist.all_gather directly, which detached the result)."""
+    return _GatherHeads.apply(x_local, H, dim, group)
+
+
 class HeadShardedFFTConv(torch.nn.Module):
     """Wraps a conv callable `conv(u, k, pregate, postgate)`; each rank computes its head shard.
-    `gather=True` returns the full (B,H,L) output on every rank (all-gather over xGMI)."""
+    `gather=True` returns the full (B,H,L) output on every rank (differentiable all-gather over xGMI)."""
 
-    def __init__(self, conv, gather=False):
+    def __init__(self, conv, gather=False, group=None):
         super().__init__()
-        self.conv, self.gather = conv, gather
+        self.conv, self.gather, self.group = conv, gather, group
 
     def forward(self, u, k, pregate=None, postgate=None):
         H = u.shape[1]
-        ul, kl = shard_heads(u, 1), shard_heads(k, 0)
-        pl = None if pregate is None else shard_heads(pregate, 1)
-        ql = None if postgate is None else shard_heads(postgate, 1)
+        rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
+        ul, kl = shard_heads(u, 1, rank, world), shard_heads(k, 0, rank, world)
+        pl = None if pregate is None else shard_heads(pregate, 1, rank, world)
+        ql = None if postgate is None else shard_heads(postgate, 1, rank, world)
         y = self.conv(ul, kl, pl, ql) if pl is not None else self.conv(ul, kl)
-        return gather_heads(y, H, 1) if self.gather else y
+        return gather_heads(y, H, 1, self.group) if self.gather else y
+
+
+# ------------------------------------------------------------------------------------------------ B-shard
+class _HipOps:
+    """GPU backend of the B-shard: the C-ABI entry points of one fused plan."""
+
+    def __init__(self, mod, device):
+        from . import conv as C, _lib
+        self.C, self.L, self.mod = C, _lib, mod
+        self.plan = mod._get_plan(device, mod._plan_seqlen)
+
+    def kernel_fft(self, k):                       # (h, Lk) fp32 -> (h, kf_elems, 2) dtype, internal order
+        return self.C._kernel_fft(self.plan, k)
+
+    def conv(self, u, kf, pre, post):
+        return self.C._conv(self.plan, u, kf, pre, post, False)
+
+    def backward(self, dout, u, kf, pre, post):
+        """-> du, dpre, dpost, dk_f (H, kf_elems, 2) fp32 summed over the local batch"""
+        lib, L = self.L.lib(), self.L
+        B, H, Lu = u.shape
+        ws = torch.empty(lib.ffc_dkf_workspace_bytes(self.plan.handle, B, H), dtype=torch.uint8, device=u.device)
+        du = torch.empty_like(u)
+        dpre = torch.empty_like(u) if pre is not None else None
+        dpost = torch.empty_like(u) if pre is not None else None
+        L.check(lib.ffc_conv_bwd_gated(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du),
+                                       L.ptr(dpre), L.ptr(dpost), L.ptr(ws), B, H, Lu, L.stream_ptr()), "ffc_conv_bwd_gated")
+        nslab = lib.ffc_dkf_slab_count(self.plan.handle, B, H)
+        nfl = H * self.plan.kf_elems * 2
+        slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, H, self.plan.kf_elems, 2)
+        return du, dpre, dpost, (slabs[0] if nslab == 1 else slabs.sum(0))
+
+    def dk_from_dkf(self, dkf, Lk):                # (h, kf_elems, 2) fp32 -> (h, Lk) fp32
+        L = self.L
+        h = dkf.shape[0]
+        dk = torch.empty(h, Lk, dtype=torch.float32, device=dkf.device)
+        L.check(L.lib().ffc_kernel_ifft_grad_slabs(self.plan.handle, L.ptr(dkf.contiguous()), 1, h, Lk, L.ptr(dk), L.stream_ptr()),
+                "ffc_kernel_ifft_grad_slabs")
+        return dk
+
+
+class _BShardFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, k, pre, post, ops, group, training):
+        H, Lk = k.shape
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        s, e = head_range(H, rank, world)
+        kf_local = ops.kernel_fft(k.detach()[s:e].to(torch.float32).contiguous())
+        kf = _all_gather_uneven(kf_local, H, 0, group)                # the path's one forward collective
+        u = u.contiguous()
+        pre = None if pre is None else pre.contiguous()
+        post = None if post is None else post.contiguous()
+        out = ops.conv(u, kf, pre, post)
+        ctx.ops, ctx.group, ctx.Lk, ctx.k_dtype, ctx.gated = ops, group, Lk, k.dtype, pre is not None
+        if training:
+            ctx.save_for_backward(*((u, kf, pre, post) if pre is not None else (u, kf)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.saved_tensors:
+            raise RuntimeError("BatchShardedFFTConv: backward needs module.training=True at forward time")
+        if ctx.gated:
+            u, kf, pre, post = ctx.saved_tensors
+        else:
+            (u, kf), pre, post = ctx.saved_tensors, None, None
+        import contextlib
+        with (torch.cuda.device(u.device) if u.is_cuda else contextlib.nullcontext()):
+            du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post)
+            H = dkf.shape[0]
+            dkf_local = _reduce_scatter_heads(dkf.contiguous(), 0, ctx.group)   # fp32 sums over every rank's batch rows
+            dk_local = ctx.ops.dk_from_dkf(dkf_local, ctx.Lk)
+            dk = _all_gather_uneven(dk_local, H, 0, ctx.group)        # replicated parameter -> full gradient everywhere
+        return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None
+
+
+class _AllReduceGrad(torch.autograd.Function):
+    """identity whose gradient is summed over the ranks (a replicated parameter used on every rank's batch shard)"""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+class BatchShardedFFTConv(torch.nn.Module):
+    """Data-parallel FlashFFTConv: `forward(u_local, k, pregate_local, postgate_local)` with u/gates the rank's batch
+    rows and k the full replicated (H, Lk) filter; returns the local rows of y.  k.grad is the gradient summed over ALL
+    ranks' batch rows (identical on every rank).  See the module docstring for the two modes."""
+
+    def __init__(self, conv, mode="allgather_kf", group=None, ops=None):
+        super().__init__()
+        assert mode in ("allgather_kf", "recompute")
+        self.conv, self.mode, self.group, self._ops = conv, mode, group, ops
+
+    def forward(self, u, k, pregate=None, postgate=None):
+        if pregate is not None or postgate is not None:
+            assert pregate is not None and postgate is not None
+        mode = self.mode
+        if self._ops is None and mode == "allgather_kf":
+            from . import bigfft
+            if self.conv.seqlen in bigfft.BIG_FACTORS or self.conv._folded or self.conv._kf_keep is not None:
+                mode = "recompute"          # k_f of these sizes is not a single fused plan's tensor
+        if mode == "recompute":
+            kk = _AllReduceGrad.apply(k, self.group)
+            return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
+        ops = self._ops if self._ops is not None else _HipOps(self.conv, u.device)
+        training = self.conv.training if hasattr(self.conv, "training") else True
+        if self._ops is None:
+            from .conv import _check_inputs
+            _check_inputs(self.conv, u, k, (pregate, postgate))
+            with torch.cuda.device(u.device):
+                return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training)
+        return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training)

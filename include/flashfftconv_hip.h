@@ -26,6 +26,9 @@ const char* ffc_last_error(void);
  * Replaces FlashFFTConv.__init__'s register_buffer tables (flashfftconv/conv.py:72-551). */
 int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out);
 void ffc_plan_destroy(ffc_plan* plan);
+/* Tuning knobs (FFC_FLAGS, FFC_STREAM, FFC_PERSIST, FFC_WG_MULT) are read from the environment once, by ffc_plan_create;
+ * this re-reads them into an existing plan (A/B tuning scripts).  No launch path calls getenv. */
+void ffc_plan_reload_env(ffc_plan* plan);
 /* Complex elements per head of k_f in the plan's internal ("Monarch") order. */
 int64_t ffc_plan_kf_elems(const ffc_plan* plan);
 /* internal position -> natural frequency index, ffc_plan_kf_elems() int32 entries (host memory). */
@@ -68,6 +71,10 @@ int ffc_conv_bwd_gated(const ffc_plan* plan, const void* dout, const void* u, co
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);
+/* Same from `nslab` caller-owned fp32 slabs [nslab][H][kf_elems][2]: callers that reduce the partial sums themselves
+ * (multi-GPU B-shard, flashfftconv/sharding.py: reduce-scatter of dk_f over RCCL, then H/W heads per rank). */
+int ffc_kernel_ifft_grad_slabs(const ffc_plan* plan, const void* slabs, int64_t nslab, int64_t H, int64_t Lk, float* dk,
+                               void* stream);
 
 /* FFT sizes 65536..4194304 = one or two outer DFT levels (factor n0 = 16 or 32) through HBM around a
  * fused inner size (replaces butterfly_{,padded_}{,gated_}{,ifft_}*forward, monarch.cpp:41-56, and the

@@ -37,8 +37,14 @@ def main():
         (4096, 4096, 2, 2, torch.float16, False), (8192, 4096, 2, 2, torch.bfloat16, False),
         (16384, 8192, 2, 2, torch.bfloat16, True), (32768, 16384, 2, 2, torch.bfloat16, False),
         (32768, 32768, 1, 2, torch.float16, True),
+        # fft sizes >= 65536 (outer levels through HBM), gated, unit-scale gates: L = N/2 and L = N/4
+        (65536, 32768, 2, 2, torch.bfloat16, True), (262144, 65536, 1, 1, torch.float16, True),
     ]
+    only_new = "--only-new" in sys.argv
     for (N, L, B, H, dtype, gated) in cases:
+        name = f"conv_N{N}_L{L}_B{B}_H{H}_{str(dtype).split('.')[-1]}_{'gated' if gated else 'plain'}.npz"
+        if only_new and os.path.exists(os.path.join(OUT, name)):
+            continue
         g = torch.Generator().manual_seed(N + L + B)
         u = (torch.randn(B, H, L, generator=g).to(dtype) * 0.02)
         k = torch.randn(H, L, generator=g) * 0.02 * torch.exp(-0.1 * torch.arange(L))
@@ -67,7 +73,8 @@ def main():
         name = f"conv_N{N}_L{L}_B{B}_H{H}_{d['dtype']}_{'gated' if gated else 'plain'}.npz"
         np.savez_compressed(os.path.join(OUT, name), **d)
         print("wrote", name)
-    sparse_golden()
+    if not only_new:
+        sparse_golden()
 
 
 def sparse_golden():

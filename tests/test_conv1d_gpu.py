@@ -1,62 +1,107 @@
-"""GPU parity for the short depthwise conv1d (reference tests/test_conv1d.py re-stated)."""
+"""GPU parity for the short depthwise conv1d: the reference's tests/test_conv1d.py re-stated IN FULL
+(b x h x l x k x dtype-pair matrix of :8-12, :58-62, :111-115, :166-170; forward atol 1e-1, backward atol 1) with
+relative-L2 gates against nn.Conv1d evaluated in fp32 on the same rounded inputs, plus BASELINE configs[4] at its
+exact shape, the bf16 backward the reference skips, odd shapes and non-"same" paddings.  Through the C-ABI."""
 import pytest
 import torch
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
+FWD_DTYPES = [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float16, torch.float16),
+              (torch.float16, torch.float32), (torch.float32, torch.float32), (torch.float32, torch.float16),
+              (torch.float32, torch.bfloat16)]                                      # reference test_conv1d.py:12
+BWD_DTYPES = [(torch.float16, torch.float16), (torch.float16, torch.float32), (torch.float32, torch.float32),   # reference :115
+              (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32)]    # + bf16 (skipped upstream)
+ID = lambda p: f"{str(p[0])[6:]}-{str(p[1])[6:]}"
 
-def make(b, d, l, k, in_dtype, w_dtype, is_bhl):
+
+def make(b, d, l, k, in_dtype, w_dtype, is_bhl, pad=None):
     from flashfftconv import FlashDepthWiseConv1d
     torch.manual_seed(42)
-    pad = k // 2
+    pad = k // 2 if pad is None else pad
     ref = nn.Conv1d(d, d, k, groups=d, padding=pad).to("cuda")
+    # the module holds the weights in w_dtype: the fp32 reference gets the same rounded values
+    with torch.no_grad():
+        ref.weight.copy_(ref.weight.to(w_dtype).float()); ref.bias.copy_(ref.bias.to(w_dtype).float())
     x = torch.randn(b, d, l, device="cuda")
     m = FlashDepthWiseConv1d(d, k, pad, ref.weight.detach(), ref.bias.detach(), is_bhl=is_bhl, device="cuda", dtype=w_dtype)
     return ref, m, x
 
 
-@pytest.mark.parametrize("in_dtype,w_dtype", [(torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16),
-                                              (torch.float32, torch.float32), (torch.bfloat16, torch.float32),
-                                              (torch.float16, torch.float32), (torch.float16, torch.bfloat16)])
-@pytest.mark.parametrize("k", [3, 5, 7])
-@pytest.mark.parametrize("b,d,l", [(2, 768, 1024), (4, 1024, 2048), (1, 2048, 8192), (3, 72, 1000)])
-@pytest.mark.parametrize("is_bhl", [True, False])
-def test_conv1d_fwd(b, d, l, k, in_dtype, w_dtype, is_bhl):
-    ref, m, x = make(b, d, l, k, in_dtype, w_dtype, is_bhl)
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
+
+
+def check_fwd(b, d, l, k, in_dtype, w_dtype, is_bhl, pad=None):
+    ref, m, x = make(b, d, l, k, in_dtype, w_dtype, is_bhl, pad)
     with torch.no_grad():
         y_ref = ref(x.to(in_dtype).float())
         xin = x.to(in_dtype)
         y = m(xin if is_bhl else xin.transpose(1, 2).contiguous())
         if not is_bhl:
             y = y.transpose(1, 2)
-    assert y.dtype == in_dtype
+    assert y.dtype == in_dtype and y.shape == y_ref.shape
     assert torch.allclose(y.float(), y_ref, atol=1e-1)             # reference tolerance (test_conv1d.py:53-55)
-    tol = {torch.float32: 1e-5, torch.float16: 3e-3, torch.bfloat16: 2e-2}[in_dtype]
-    wtol = {torch.float32: 0, torch.float16: 1e-3, torch.bfloat16: 8e-3}[w_dtype]
-    assert ((y.float() - y_ref).norm() / y_ref.norm()).item() < tol + wtol
+    tol = {torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[in_dtype]   # one rounding of the output
+    assert rel(y, y_ref) < tol, f"rel-L2 {rel(y, y_ref):.3e}"
 
 
-@pytest.mark.parametrize("in_dtype,w_dtype", [(torch.float16, torch.float16), (torch.float16, torch.float32),
-                                              (torch.float32, torch.float32), (torch.bfloat16, torch.float32)])
-@pytest.mark.parametrize("k", [3, 7])
-@pytest.mark.parametrize("b,d,l", [(2, 768, 1024), (3, 72, 1000)])
-@pytest.mark.parametrize("is_bhl", [True, False])
-def test_conv1d_bwd(b, d, l, k, in_dtype, w_dtype, is_bhl):
-    ref, m, x = make(b, d, l, k, in_dtype, w_dtype, is_bhl)
+def check_bwd(b, d, l, k, in_dtype, w_dtype, is_bhl, pad=None):
+    ref, m, x = make(b, d, l, k, in_dtype, w_dtype, is_bhl, pad)
     xq = x.to(in_dtype).detach().clone()
     xr = xq.float().detach().clone().requires_grad_(True)
     y_ref = ref(xr)
-    dout = torch.randn_like(y_ref)
-    y_ref.backward(dout)
+    dout = torch.randn_like(y_ref).to(in_dtype)
+    y_ref.backward(dout.float())
     xin = (xq if is_bhl else xq.transpose(1, 2)).contiguous().detach().clone().requires_grad_(True)
     y = m(xin)
-    y.backward((dout if is_bhl else dout.transpose(1, 2).contiguous()).to(in_dtype))
+    y.backward(dout if is_bhl else dout.transpose(1, 2).contiguous())
     dx = xin.grad if is_bhl else xin.grad.transpose(1, 2)
     dw = m.weights.grad if is_bhl else m.weights.grad.transpose(0, 1)
-    rel = lambda a, bb: ((a.float() - bb.float()).norm() / bb.float().norm()).item()
-    tol = {torch.float32: 1e-4, torch.float16: 4e-3, torch.bfloat16: 3e-2}[in_dtype]
-    assert rel(dx, xr.grad) < tol
-    assert rel(dw, ref.weight.grad.squeeze(1)) < tol + 2e-3
-    assert rel(m.bias.grad, ref.bias.grad) < tol + 2e-3
-    assert torch.allclose(dx.float(), xr.grad, atol=1)             # reference tolerance (test_conv1d.py:161-163)
+    tol = {torch.float32: 1e-4, torch.float16: 1e-3, torch.bfloat16: 8e-3}[in_dtype]     # du: one rounding
+    wtol = {torch.float32: 1e-4, torch.float16: 1e-3, torch.bfloat16: 8e-3}[w_dtype]     # dw/dbias: fp32 sums, rounded to w_dtype
+    assert rel(dx, xr.grad) < tol, f"du {rel(dx, xr.grad):.3e}"
+    assert rel(dw, ref.weight.grad.squeeze(1)) < wtol, f"dw {rel(dw, ref.weight.grad.squeeze(1)):.3e}"
+    assert rel(m.bias.grad, ref.bias.grad) < wtol, f"dbias {rel(m.bias.grad, ref.bias.grad):.3e}"
+    assert torch.allclose(dx.float(), xr.grad, atol=1)             # reference tolerances (test_conv1d.py:161-163)
+    assert torch.allclose(dw.float(), ref.weight.grad.squeeze(1), atol=1)
+    assert torch.allclose(m.bias.grad.float(), ref.bias.grad, atol=1)
+
+
+@pytest.mark.parametrize("dtype", FWD_DTYPES, ids=ID)
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("l", [1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("h", [768, 1024, 2048])
+@pytest.mark.parametrize("b", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("is_bhl", [True, False], ids=["bhl", "blh"])
+def test_conv1d_fwd(is_bhl, b, h, l, k, dtype):
+    check_fwd(b, h, l, k, dtype[0], dtype[1], is_bhl)
+
+
+@pytest.mark.parametrize("dtype", BWD_DTYPES, ids=ID)
+@pytest.mark.parametrize("k", [3, 5, 7])
+@pytest.mark.parametrize("l", [1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("d", [768, 1024, 2048])
+@pytest.mark.parametrize("b", [1, 2, 4, 8])
+@pytest.mark.parametrize("is_bhl", [True, False], ids=["bhl", "blh"])
+def test_conv1d_bwd(is_bhl, b, d, l, k, dtype):
+    check_bwd(b, d, l, k, dtype[0], dtype[1], is_bhl)
+
+
+def test_conv1d_baseline_config5_exact():
+    """BASELINE.json configs[4]: FlashDepthWiseConv1d k=3, B=64 H=2048 L=8192 bf16, forward + backward."""
+    check_fwd(64, 2048, 8192, 3, torch.bfloat16, torch.bfloat16, True)
+    check_bwd(64, 2048, 8192, 3, torch.bfloat16, torch.bfloat16, True)
+
+
+@pytest.mark.parametrize("is_bhl", [True, False], ids=["bhl", "blh"])
+@pytest.mark.parametrize("b,d,l,k,pad", [(3, 72, 1000, 3, None), (2, 9, 37, 5, None), (1, 130, 8, 7, None),
+                                         (2, 64, 1024, 3, 0), (2, 64, 1024, 3, 2), (2, 64, 1024, 7, 0), (2, 64, 1024, 7, 6),
+                                         (2, 64, 1024, 5, 12), (3, 40, 250, 5, 4)])
+def test_conv1d_odd_shapes_and_paddings(is_bhl, b, d, l, k, pad):
+    """ragged sizes (generic path) and paddings 0 .. K-1 and beyond (L_out = L + 2p - K + 1, conv1d.h:48-95): the C-ABI
+    accepts any P, so the vectorised path's register window must be guarded (round-1 advisor finding)."""
+    for in_dtype, w_dtype in ((torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32)):
+        check_fwd(b, d, l, k, in_dtype, w_dtype, is_bhl, pad)
+        check_bwd(b, d, l, k, in_dtype, w_dtype, is_bhl, pad)

@@ -85,8 +85,10 @@ def run_case(B, H, seqlen, dtype, padded, gated):
         out_b = conv(u, k, pre, post) if gated else conv(u, k)
     assert torch.equal(out, out_b), f"HIP forward not reproducible: {int((out != out_b).sum())} elements differ"
     assert torch.allclose(out, ref, atol=1e-2)                      # reference assert (:83)
-    if not gated:
-        assert rel(out, ref) < REL[dtype]
+    # relative gate on every output, gated or not (the reference's *0.02 gates make `atol` alone vacuous: |out| ~ 5e-7).
+    # Gated: two more roundings to the activation dtype (u*pregate, y*postgate).
+    GREL = {k: v * (1.5 if gated else 1.0) for k, v in REL.items()}
+    assert rel(out, ref) < GREL[dtype], f"out rel-L2 {rel(out, ref):.3e}"
     dout = torch.randn_like(out) * 0.02
     gref = stable(lambda: torch.autograd.grad(ref, leaves_c, dout.clone(), retain_graph=True), "backward")
     leaves = (u, k, pre, post) if gated else (u, k)
@@ -96,54 +98,62 @@ def run_case(B, H, seqlen, dtype, padded, gated):
         assert torch.equal(a, b), f"HIP backward ({name}) not reproducible: {int((a != b).sum())} elements differ"
     assert torch.allclose(g[0], gref[0], atol=1e-2)                 # reference assert (:103)
     assert torch.allclose(g[1], gref[1], atol=1e-1)                 # reference ktol (:105-107)
-    if not gated:
-        assert rel(g[0], gref[0]) < REL[dtype]
-        # dk: SURVEY 8(c)(iii) gate is 2e-2 for both dtypes; the dk_f -> dk inverse always runs in bf16 operand
-        # arithmetic (fp32 range for the unnormalised sums), so fp16 modules see ~5e-3 there, not fp16's ~1e-3
-        assert rel(g[1], gref[1]) < max(REL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0))
-    else:
+    assert rel(g[0], gref[0]) < GREL[dtype], f"du rel-L2 {rel(g[0], gref[0]):.3e}"
+    # dk: SURVEY 8(c)(iii) gate is 2e-2 for both dtypes; the dk_f -> dk inverse always runs in bf16 operand
+    # arithmetic (fp32 range for the unnormalised sums), so fp16 modules see ~5e-3 there, not fp16's ~1e-3
+    dk_tol = max(GREL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0) * (1.5 if gated else 1.0))
+    assert rel(g[1], gref[1]) < dk_tol, f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
+    if gated:
         assert torch.allclose(g[2], gref[2], atol=1e-2)             # reference (:242-243)
         assert torch.allclose(g[3], gref[3], atol=1e-2)
-        # *0.02 gates make fp16 outputs subnormal; relative gates use the fp32 reference scale
-        assert rel(g[1], gref[1]) < 2 * REL[dtype]
+        assert rel(g[2], gref[2]) < GREL[dtype], f"dpregate rel-L2 {rel(g[2], gref[2]):.3e}"
+        assert rel(g[3], gref[3]) < GREL[dtype], f"dpostgate rel-L2 {rel(g[3], gref[3]):.3e}"
 
 
-@pytest.mark.parametrize("seqlen", SEQLENS)
+# The reference matrix in full (tests/test_flashfftconv.py:48-51, :109-112, :168-171, :249-252): B in {1,2,4,8,64},
+# H in {768,111}, both dtypes, every fft size 256 .. 4194304 (B and H capped by the reference's own set_B_H), plus
+# fft 2048, which the reference supports (README.md:268) but does not test.
+ALL_SEQLENS = SEQLENS + BIG
+REF_B = [1, 2, 4, 8, 64]
+REF_H = [768, 111]
+
+
+@pytest.mark.parametrize("seqlen", ALL_SEQLENS)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H", [768, 111])
-@pytest.mark.parametrize("B", [1, 2, 8])
+@pytest.mark.parametrize("H", REF_H)
+@pytest.mark.parametrize("B", REF_B)
 def test_flash_fft_conv(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=False, gated=False)
 
 
-@pytest.mark.parametrize("seqlen", SEQLENS)
+@pytest.mark.parametrize("seqlen", ALL_SEQLENS)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("H", [768, 111])
-@pytest.mark.parametrize("B", [1, 4])
+@pytest.mark.parametrize("H", REF_H)
+@pytest.mark.parametrize("B", REF_B)
 def test_flash_fft_conv_padded(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=True, gated=False)
 
 
-@pytest.mark.parametrize("seqlen", SEQLENS)
+@pytest.mark.parametrize("seqlen", ALL_SEQLENS)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,H", [(2, 768), (5, 111)])
+@pytest.mark.parametrize("H", REF_H)
+@pytest.mark.parametrize("B", REF_B)
 def test_flash_fft_conv_gating(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=False, gated=True)
 
 
-@pytest.mark.parametrize("seqlen", SEQLENS)
+@pytest.mark.parametrize("seqlen", ALL_SEQLENS)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,H", [(2, 768), (3, 111)])
+@pytest.mark.parametrize("H", REF_H)
+@pytest.mark.parametrize("B", REF_B)
 def test_flash_fft_conv_gating_padded(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=True, gated=True)
 
 
-@pytest.mark.parametrize("seqlen", BIG)
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("padded,gated", [(False, False), (True, False), (False, True), (True, True)])
-def test_flash_fft_conv_big(seqlen, dtype, padded, gated):
-    """N >= 65536 (reference tests/test_flashfftconv.py parametrisation up to 128*32768)."""
-    run_case(2, 32 if seqlen <= 1048576 else 16, seqlen, dtype, padded=padded, gated=gated)
+@pytest.mark.parametrize("B,H,seqlen", [(5, 111, 4096), (3, 111, 32768), (3, 7, 65536), (5, 3, 1048576)])
+def test_odd_batches_gated(B, H, seqlen):
+    """odd batch sizes (a half-empty packed pair) are not in the reference matrix"""
+    run_case(B, H, seqlen, torch.bfloat16, padded=True, gated=True)
 
 
 def test_big_odd_batch_small_heads():
@@ -156,7 +166,24 @@ def test_unit_scale_gated_relative():
     from flashfftconv import FlashFFTConv
     torch.manual_seed(1)
     for N, dtype in ((1024, torch.bfloat16), (16384, torch.float16), (32768, torch.bfloat16)):
-        B, H, L = 4, 32, N // 2
+        _unit_scale_gated(N, dtype, 4, 32, N // 2)
+
+
+@pytest.mark.parametrize("N,dtype,B,H,L", [(65536, torch.bfloat16, 4, 32, 32768), (65536, torch.float16, 3, 16, 65536),
+                                           (131072, torch.bfloat16, 2, 16, 65536), (262144, torch.float16, 2, 16, 100000),
+                                           (1048576, torch.bfloat16, 2, 16, 524288), (2097152, torch.float16, 2, 8, 2097152),
+                                           (4194304, torch.bfloat16, 2, 16, 1048576), (4194304, torch.float16, 1, 4, 2097152)])
+def test_unit_scale_gated_relative_big(N, dtype, B, H, L):
+    """The same for fft sizes >= 65536 (HBM-level outer passes + fused kernel): every gated output and gradient has a
+    relative gate (round 1 only had atol=1e-2 here, which zeros would pass)."""
+    _unit_scale_gated(N, dtype, B, H, L, big=True)
+
+
+def _unit_scale_gated(N, dtype, B, H, L, big=False):
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(1)
+    f = 2.0 if big else 1.0          # two more roundings per outer level, as in run_case
+    if True:
         u, pre, post = (torch.randn(B, H, L, device="cuda").to(dtype).requires_grad_(True) for _ in range(3))
         k = (torch.randn(H, L, device="cuda") * 0.1).requires_grad_(True)
         c = [t.detach().clone().requires_grad_(True) for t in (u, k, pre, post)]
@@ -164,9 +191,56 @@ def test_unit_scale_gated_relative():
         ref = ref_fft_conv(c[0] * c[2], c[1], n=N) * c[3]
         dout = torch.randn_like(out)
         out.backward(dout); ref.backward(dout.clone())
-        assert rel(out, ref) < REL[dtype]
-        for a, b in zip((u, k, pre, post), c):
-            assert rel(a.grad, b.grad) < 1.5 * REL[dtype]
+        assert rel(out, ref) < f * REL[dtype], f"out {rel(out, ref):.3e}"
+        for name, a, b in zip(("du", "dk", "dpregate", "dpostgate"), (u, k, pre, post), c):
+            e = rel(a.grad, b.grad)
+            assert e < 1.5 * f * (max(REL[dtype], 1e-2) if name == "dk" else REL[dtype]), f"{name} {e:.3e}"
+
+
+def _chunked_reference(u, k, pre, post, dout, N, hc):
+    """fp32 torch.fft oracle with autograd, evaluated in head chunks of `hc` (bounds the complex64 temporaries)."""
+    H = u.shape[1]
+    outs, grads = [], [[] for _ in range(4 if pre is not None else 2)]
+    for h0 in range(0, H, hc):
+        sl = slice(h0, min(H, h0 + hc))
+        leaves = [u[:, sl].detach().clone().requires_grad_(True), k[sl].detach().clone().requires_grad_(True)]
+        if pre is not None:
+            leaves += [pre[:, sl].detach().clone().requires_grad_(True), post[:, sl].detach().clone().requires_grad_(True)]
+            ref = ref_fft_conv(leaves[0] * leaves[2], leaves[1], n=N) * leaves[3]
+        else:
+            ref = ref_fft_conv(leaves[0], leaves[1], n=N)
+        g = torch.autograd.grad(ref, leaves, dout[:, sl])
+        outs.append(ref.detach())
+        for i, t in enumerate(g):
+            grads[i].append(t)
+    cat = lambda ts, d: torch.cat(ts, dim=d)
+    return cat(outs, 1), [cat(grads[0], 1), cat(grads[1], 0)] + [cat(x, 1) for x in grads[2:]]
+
+
+@pytest.mark.parametrize("name,N,B,H,L,gated", [("cfg2", 32768, 16, 768, 16384, False), ("cfg3", 16384, 8, 1024, 8192, True),
+                                                ("cfg4", 4194304, 1, 16, 1048576, False)])
+def test_baseline_configs_exact(name, N, B, H, L, gated):
+    """BASELINE.json configs[1..3] at their EXACT shapes (cfg4: fft 4M with L = N/4), forward + backward against the
+    torch.fft oracle with a relative-L2 gate on every output.  (configs[4], the conv1d, is in test_conv1d_gpu.py;
+    configs[0] is the CPU plumbing case of tests/test_sim_kernels.py.)"""
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(5)
+    dtype = torch.bfloat16
+    mk = lambda: torch.randn(B, H, L, device="cuda").to(dtype).requires_grad_(True)
+    u = mk()
+    k = (torch.randn(H, L, device="cuda") * 0.05).requires_grad_(True)
+    pre, post = (mk(), mk()) if gated else (None, None)
+    conv = FlashFFTConv(N, dtype=dtype).to("cuda")
+    out = conv(u, k, pre, post) if gated else conv(u, k)
+    dout = torch.randn_like(out)
+    leaves = (u, k, pre, post) if gated else (u, k)
+    g = torch.autograd.grad(out, leaves, dout)
+    ref, gref = _chunked_reference(u, k, pre, post, dout, N, 64 if N <= 32768 else 4)
+    f = (2.0 if N >= 65536 else 1.0) * (1.5 if gated else 1.0)
+    assert rel(out, ref) < f * REL[dtype], f"{name} out {rel(out, ref):.3e}"
+    for nm, a, b in zip(("du", "dk", "dpregate", "dpostgate"), g, gref):
+        e = rel(a, b)
+        assert e < f * REL[dtype], f"{name} {nm} {e:.3e}"
 
 
 GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_*.npz")))
@@ -186,10 +260,10 @@ def test_golden_vectors(path):
     else:
         out = conv(u, k)
     out.backward(t("dout", dtype))
-    tol = REL[dtype]
+    tol = REL[dtype] * (2.0 if N >= 65536 else 1.0)
     assert rel(out, t("out", torch.float32)) < tol
     assert rel(u.grad, t("du", torch.float32)) < tol
-    assert rel(k.grad, t("dk", torch.float32)) < tol
+    assert rel(k.grad, t("dk", torch.float32)) < max(tol, 1e-2)
     if int(g["gated"]):
         assert rel(pre.grad, t("dpre", torch.float32)) < tol
         assert rel(post.grad, t("dpost", torch.float32)) < tol

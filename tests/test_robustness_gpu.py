@@ -1,12 +1,12 @@
 """Robustness of the HIP path against state it does not own (run as scripts so that torch.empty can be patched
 process-wide): results must not depend on (a) what the previous workgroup left in a CU's LDS / vector / accumulation
-registers (tests/gpu_poison.py, ffc_debug_poison) or (b) the previous contents of any buffer the Python layer
-allocates (tests/gpu_uninit.py pre-fills every torch.empty with NaN bit patterns)."""
+registers (benchmarks/gpu_poison.py, ffc_debug_poison) or (b) the previous contents of any buffer the Python layer
+allocates (benchmarks/gpu_uninit.py pre-fills every torch.empty with NaN bit patterns)."""
 import os, subprocess, sys
 import pytest
 
 pytestmark = pytest.mark.gpu
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchmarks")
 
 
 @pytest.mark.parametrize("script,done", [("gpu_poison.py", "poison stress done, mismatching tensors: 0"),

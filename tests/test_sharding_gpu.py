@@ -1,0 +1,92 @@
+"""The multi-GPU wrappers (flashfftconv/sharding.py) around the PRODUCT: two ranks, one process each, both on cuda:0 of
+the 1-GPU test box (the same hook bench.py has: FFC_BENCH_SAME_GPU), gloo as the transport because RCCL refuses two ranks
+on one device.  Each rank compares its sharded HIP result with the single-rank HIP result of the same inputs
+(forward bitwise: rows are independent; dk to 1e-3: the order of the fp32 partial sums differs) and with the torch.fft
+oracle.  On a real node the only difference is backend="nccl" (RCCL over xGMI) and one device per rank."""
+import os, socket
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        _body(rank, world, port, q)
+    except Exception:
+        import traceback
+        q.put((rank, {"exception: " + traceback.format_exc()[-2000:]: False}))
+
+
+def _body(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "flash-fft-conv_amd"), root]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from flashfftconv import FlashFFTConv
+    from flashfftconv.sharding import HeadShardedFFTConv, BatchShardedFFTConv, head_range
+    from oracle.torch_ref import ref_fft_conv
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    ok = {}
+    dev = torch.device("cuda", 0)
+    for (N, B, H, L, gated) in ((4096, 4, 16, 2048, False), (32768, 4, 10, 16384, True), (1024, 8, 7, 1024, False),
+                                (65536, 4, 6, 32768, False)):
+        torch.manual_seed(7)                      # same inputs on both ranks
+        dt = torch.bfloat16
+        mk = lambda: torch.randn(B, H, L, device=dev).to(dt)
+        u, dout = mk(), mk()
+        k = torch.randn(H, L, device=dev) * 0.1
+        gates = [mk(), mk()] if gated else []
+        mod = FlashFFTConv(N, dtype=dt).to(dev)
+        # single-rank HIP result + oracle
+        lv = [t.clone().requires_grad_(True) for t in [u, k] + gates]
+        full = mod(*lv)
+        gfull = torch.autograd.grad(full, lv, dout)
+        lo = [t.clone().requires_grad_(True) for t in [u, k] + gates]
+        oref = ref_fft_conv(lo[0] * lo[2], lo[1], N) * lo[3] if gated else ref_fft_conv(lo[0], lo[1], N)
+        goref = torch.autograd.grad(oref, lo, dout)
+        tag = f"N{N}"
+        # ---- H-shard with the differentiable gather
+        hv = [t.clone().requires_grad_(True) for t in [u, k] + gates]
+        y = HeadShardedFFTConv(mod, gather=True)(*hv)
+        ok[tag + "_hshard_out_bitwise"] = torch.equal(y, full)
+        s, e = head_range(H, rank, world)
+        gy = torch.autograd.grad(y, hv, dout)     # both ranks push the same dout: shard grads are world x single-rank
+        ok[tag + "_hshard_du"] = rel(gy[0][:, s:e], world * gfull[0][:, s:e]) < 1e-2 and float(gy[0][:, :s].abs().sum()) == 0.0
+        ok[tag + "_hshard_dk"] = rel(gy[1][s:e], world * gfull[1][s:e]) < 1e-2
+        # ---- B-shard: k_f all-gather / dk_f reduce-scatter (fused sizes), recompute + all-reduce (big sizes)
+        b0, b1 = rank * B // world, (rank + 1) * B // world
+        bv = [u[b0:b1].clone().requires_grad_(True), k.clone().requires_grad_(True)] + [g[b0:b1].clone().requires_grad_(True) for g in gates]
+        for mode in (("allgather_kf", "recompute") if N <= 32768 else ("allgather_kf",)):
+            bs = BatchShardedFFTConv(mod, mode=mode)
+            yl = bs(*bv)
+            ok[f"{tag}_bshard_{mode}_out_bitwise"] = torch.equal(yl, full[b0:b1])
+            gl = torch.autograd.grad(yl, bv, dout[b0:b1])
+            ok[f"{tag}_bshard_{mode}_du_bitwise"] = torch.equal(gl[0], gfull[0][b0:b1])
+            ok[f"{tag}_bshard_{mode}_dk_vs_single"] = rel(gl[1], gfull[1]) < 2e-3        # FULL dk on every rank
+            ok[f"{tag}_bshard_{mode}_dk_vs_oracle"] = rel(gl[1], goref[1]) < 3e-2
+            if gated:
+                ok[f"{tag}_bshard_{mode}_dgates_bitwise"] = torch.equal(gl[2], gfull[2][b0:b1]) and torch.equal(gl[3], gfull[3][b0:b1])
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_sharded_product_two_ranks_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps: p.start()
+    res = [q.get(timeout=600) for _ in ps]
+    for p in ps: p.join(60)
+    for rank, ok in res:
+        bad = [k for k, v in ok.items() if not v]
+        assert not bad, (rank, bad)
