@@ -64,9 +64,12 @@ def check_bwd(b, d, l, k, in_dtype, w_dtype, is_bhl, pad=None):
     assert rel(dx, xr.grad) < tol, f"du {rel(dx, xr.grad):.3e}"
     assert rel(dw, ref.weight.grad.squeeze(1)) < wtol, f"dw {rel(dw, ref.weight.grad.squeeze(1)):.3e}"
     assert rel(m.bias.grad, ref.bias.grad) < wtol, f"dbias {rel(m.bias.grad, ref.bias.grad):.3e}"
-    assert torch.allclose(dx.float(), xr.grad, atol=1)             # reference tolerances (test_conv1d.py:161-163)
-    assert torch.allclose(dw.float(), ref.weight.grad.squeeze(1), atol=1)
-    assert torch.allclose(m.bias.grad.float(), ref.bias.grad, atol=1)
+    # reference tolerances (test_conv1d.py:161-163): atol=1.  bf16 parameters (not tested upstream) hold their gradients
+    # (|dw| ~ sqrt(B*L) = 256 .. 512 here) on a grid of 2 .. 4, so they get bf16's relative step on top
+    rt = 2.0 ** -8 if w_dtype == torch.bfloat16 else 0.0
+    assert torch.allclose(dx.float(), xr.grad, atol=1)
+    assert torch.allclose(dw.float(), ref.weight.grad.squeeze(1), atol=1, rtol=rt)
+    assert torch.allclose(m.bias.grad.float(), ref.bias.grad, atol=1, rtol=rt)
 
 
 @pytest.mark.parametrize("dtype", FWD_DTYPES, ids=ID)
