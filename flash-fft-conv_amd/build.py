@@ -63,12 +63,17 @@ def check_agpr(asm_path):
         raise RuntimeError(f"{asm_path}: compiler-allocated accumulation registers ({len(bad)} findings), e.g. {bad[:3]}")
 
 
-def build_hip(force=False, verbose=False):
-    """Compile every translation unit for gfx950 in parallel, then link the shared library."""
+def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=None):
+    """Compile every translation unit for gfx950 in parallel, then link the shared library.
+    variant: tuning build with `extra_flags` under lib/variants/<name>/ (A/B runs: FFC_LIB=<that .so>)."""
     from concurrent.futures import ThreadPoolExecutor
-    os.makedirs(LIB, exist_ok=True)
-    obj_dir = os.path.join(LIB, "obj")
+    global HIP_FLAGS
+    lib_dir = LIB if variant is None else os.path.join(LIB, "variants", variant)
+    os.makedirs(lib_dir, exist_ok=True)
+    obj_dir = os.path.join(lib_dir, "obj")
     os.makedirs(obj_dir, exist_ok=True)
+    hip_so = os.path.join(lib_dir, "libflashfftconv_hip.so")
+    flags = HIP_FLAGS + list(extra_flags)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "flashfftconv_hip.h")))
@@ -78,7 +83,7 @@ def build_hip(force=False, verbose=False):
         src = os.path.join(CSRC, f)
         out = os.path.join(obj_dir, f + (".s" if want_asm else ".o"))
         if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time):
-            cmd = [hipcc] + HIP_FLAGS + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
+            cmd = [hipcc] + flags + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -93,9 +98,9 @@ def build_hip(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(10, os.cpu_count() or 4)) as ex:
         res = [r for r, j in zip(ex.map(compile_one, jobs), jobs) if not j[1]]
     objs = [o for o, _ in res]
-    if force or any(ch for _, ch in res) or not os.path.exists(HIP_SO):
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_SO] + objs)
-    return HIP_SO
+    if force or any(ch for _, ch in res) or not os.path.exists(hip_so):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hip_so] + objs)
+    return hip_so
 
 
 def build_sim(force=False):
@@ -117,4 +122,9 @@ def build_all(force=False, verbose=False):
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
-    print(build_all(force, verbose=True))
+    if "--variant" in sys.argv:      # python build.py --variant NAME -DFFC_X=1 ...
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        extra = [a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-m")]
+        print(build_hip(force, verbose=False, variant=name, extra_flags=extra))
+    else:
+        print(build_all(force, verbose=True))

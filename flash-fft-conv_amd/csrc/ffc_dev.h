@@ -40,6 +40,10 @@ struct DevB {
   static constexpr bool HAS_TR = true;
   // element-wise complex multiply of two accumulator tuples (x (x) t or x (x) conj t): whole-vector fp32 ops,
   // which gfx950 legalises to v_pk_mul_f32 / v_pk_fma_f32 on aligned register pairs
+#ifndef FFC_NO_PK
+#define FFC_NO_PK 0
+#endif
+#if !FFC_NO_PK
   template <bool CONJ> static FFC_FN void cmul16(A16& re, A16& im, const A16& tr, const A16& ti) {
     const A16 a = re, b = im;
     if (!CONJ) { re = a * tr - b * ti; im = a * ti + b * tr; }
@@ -68,6 +72,41 @@ struct DevB {
     wr = wr + (a2 * zr + b2 * zi);
     wi = wi + (b2 * zr - a2 * zi);
   }
+#else
+  // scalar fp32 variant of the same helpers (A/B of packed vs plain VALU next to MFMAs: MI355X_MICROARCH.md prices a
+  // v_pk_fma_f32 beside MFMAs well above two v_fma_f32)
+  static FFC_FN f32 sfma(f32 a, f32 b, f32 c) { return __builtin_fmaf(a, b, c); }
+  template <bool CONJ> static FFC_FN void cmul16(A16& re, A16& im, const A16& tr, const A16& ti) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const f32 a = re[r], b = im[r];
+      if (!CONJ) { re[r] = sfma(a, tr[r], -(b * ti[r])); im[r] = sfma(a, ti[r], b * tr[r]); }
+      else { re[r] = sfma(a, tr[r], b * ti[r]); im[r] = sfma(b, tr[r], -(a * ti[r])); }
+    }
+  }
+  struct F2 { f32 x, y; };
+  static FFC_FN F2 f2(f32 a, f32 b) { F2 v; v.x = a; v.y = b; return v; }
+  static FFC_FN f32 f2_lo(F2 v) { return v.x; }
+  static FFC_FN f32 f2_hi(F2 v) { return v.y; }
+  static FFC_FN void cmulp(F2 xr, F2 xi, f32 wr, f32 wi, F2& yr, F2& yi) {
+    yr.x = sfma(xr.x, wr, -(xi.x * wi)); yr.y = sfma(xr.y, wr, -(xi.y * wi));
+    yi.x = sfma(xr.x, wi, xi.x * wr); yi.y = sfma(xr.y, wi, xi.y * wr);
+  }
+  template <bool CONJ>
+  static FFC_FN void cmul2v(A16& re, A16& im, int r0, F2 tr, F2 ti) {
+    const f32 t_r[2] = {tr.x, tr.y}, t_i[2] = {ti.x, ti.y};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const f32 a = re[r0 + q], b = im[r0 + q];
+      if (!CONJ) { re[r0 + q] = sfma(a, t_r[q], -(b * t_i[q])); im[r0 + q] = sfma(a, t_i[q], b * t_r[q]); }
+      else { re[r0 + q] = sfma(a, t_r[q], b * t_i[q]); im[r0 + q] = sfma(b, t_r[q], -(a * t_i[q])); }
+    }
+  }
+  static FFC_FN void cmac2_conj(F2& wr, F2& wi, const A16& a, const A16& b, int r0, F2 zr, F2 zi) {
+    wr.x = wr.x + sfma(a[r0], zr.x, b[r0] * zi.x); wr.y = wr.y + sfma(a[r0 + 1], zr.y, b[r0 + 1] * zi.y);
+    wi.x = wi.x + sfma(b[r0], zr.x, -(a[r0] * zi.x)); wi.y = wi.y + sfma(b[r0 + 1], zr.y, -(a[r0 + 1] * zi.y));
+  }
+#endif
   // Accumulation registers a0..a127 addressed by number (see Modes::WAcc).  The kernel marks them used once
   // (agpr_reserve) so that the kernel descriptor allocates them; the compiler itself never places values there
   // (MFMAs are kept in VGPR form, build flag -mllvm --amdgpu-mfma-vgpr-form; build.py checks the disassembly).
@@ -93,13 +132,18 @@ struct DevB {
   // rows r0, r0+1 of (re,im) times (t0,t1) (or its conjugate): one packed mul + one packed fma per output pair
   template <bool CONJ>
   static FFC_FN void cmul2(A16& re, A16& im, int r0, f32 tr0, f32 tr1, f32 ti0, f32 ti1) {
-    const f32x2 a = {re[r0], re[r0 + 1]}, b = {im[r0], im[r0 + 1]}, tr = {tr0, tr1}, ti = {ti0, ti1};
-    f32x2 x, y;
-    if (!CONJ) { x = a * tr - b * ti; y = a * ti + b * tr; }
-    else { x = a * tr + b * ti; y = b * tr - a * ti; }
-    re[r0] = x.x; re[r0 + 1] = x.y; im[r0] = y.x; im[r0 + 1] = y.y;
+    cmul2v<CONJ>(re, im, r0, f2(tr0, tr1), f2(ti0, ti1));
   }
+#if !FFC_NO_PK
   static FFC_FN A16 a16_scale(const A16& a, float s) { return a * s; }
+#else
+  static FFC_FN A16 a16_scale(const A16& a, float s) {
+    A16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = a[r] * s;
+    return o;
+  }
+#endif
   static FFC_FN A16 a16_zero() { A16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; return z; }
   static FFC_FN W4 w4(u32 a, u32 b, u32 c, u32 e) { W4 v = {a, b, c, e}; return v; }
 

@@ -71,7 +71,10 @@ def _body(rank, world, port, q):
             ok[f"{tag}_bshard_{mode}_out_bitwise"] = torch.equal(yl, full[b0:b1])
             gl = torch.autograd.grad(yl, bv, dout[b0:b1])
             ok[f"{tag}_bshard_{mode}_du_bitwise"] = torch.equal(gl[0], gfull[0][b0:b1])
-            ok[f"{tag}_bshard_{mode}_dk_vs_single"] = rel(gl[1], gfull[1]) < 2e-3        # FULL dk on every rank
+            # FULL dk on every rank.  allgather_kf: one inverse of the reduced fp32 sums, like the single-rank run;
+            # recompute: each rank inverts ITS partial sums (bf16 operands, 2^-9) and the results are all-reduced
+            dk_tol = 2e-3 if (mode == "allgather_kf" and N <= 32768) else 8e-3
+            ok[f"{tag}_bshard_{mode}_dk_vs_single"] = rel(gl[1], gfull[1]) < dk_tol
             ok[f"{tag}_bshard_{mode}_dk_vs_oracle"] = rel(gl[1], goref[1]) < 3e-2
             if gated:
                 ok[f"{tag}_bshard_{mode}_dgates_bitwise"] = torch.equal(gl[2], gfull[2][b0:b1]) and torch.equal(gl[3], gfull[3][b0:b1])
