@@ -543,8 +543,11 @@ struct Body {
     }
   }
 
-  // tile-pair variant: 32-bit LDS accesses shared by two column tiles (fewer LDS instructions, more VALU
-  // split/merge work and registers)
+  // tile-pair variant: 32-bit LDS accesses shared by two column tiles.  Dword tp of each 8-byte chunk holds elements
+  // (2tp, 2tp+1) of a row = the same row of the two tiles: operand dwords are one 16-bit-half merge each
+  // (B::merge_lo / merge_hi = v_perm_b32), and the results go back as one v_cvt_pk(tile 2tp, tile 2tp+1) per row and plane
+  // (the first tile's fp32 accumulators wait for the second tile's instead of a stash of packed halves).
+  // No length masks: every E row this stage reads was written by rows_store, zero beyond L (HALF never reads rows >= 16).
   template <bool FWD, bool HALF>
   static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f) {
     const i32 lane = B::opaque(B::lane());
@@ -562,7 +565,6 @@ struct Body {
     lds_mat(F1, GEO::L_F1);
 #pragma unroll 1
     for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): a runtime loop bounds the live ranges
-      // raw rows of this tile pair: dword tp of each 8-byte chunk (elements 2tp, 2tp+1 = the two tiles)
       u32 rawr[2][8], rawi[2][8];
 #pragma unroll
       for (int ms = 0; ms < 2; ms++) {
@@ -572,16 +574,10 @@ struct Body {
           const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
           const int s1 = c / GEO::N1, rwc = c % GEO::N1;
           i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
-          u32 vr = B::lds_r32(off), vi = B::lds_r32(off + GEO::PLANE);
-          if (FWD) {
-            pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
-            vr = B::sel(ok, vr, B::uconst(0));
-            vi = B::sel(ok, vi, B::uconst(0));
-          }
-          rawr[ms][e] = vr; rawi[ms][e] = vi;
+          rawr[ms][e] = B::lds_r32(off); rawi[ms][e] = B::lds_r32(off + GEO::PLANE);
         }
       }
-      u32 sre[16], sim[16];
+      A16 re0, im0;
 #pragma unroll
       for (int th = 0; th < 2; th++) {
         Op op;
@@ -590,9 +586,8 @@ struct Body {
           if (ms >= ms_lim) continue;
 #pragma unroll
           for (int d = 0; d < 4; d++) {
-            u32 ar = rawr[ms][2 * d], br = rawr[ms][2 * d + 1], ai = rawi[ms][2 * d], bi = rawi[ms][2 * d + 1];
-            op.r[ms][d] = th ? ((ar >> 16) | (br & 0xffff0000u)) : ((ar & 0xffffu) | (br << 16));
-            op.i[ms][d] = th ? ((ai >> 16) | (bi & 0xffff0000u)) : ((ai & 0xffffu) | (bi << 16));
+            op.r[ms][d] = th ? B::merge_hi(rawr[ms][2 * d], rawr[ms][2 * d + 1]) : B::merge_lo(rawr[ms][2 * d], rawr[ms][2 * d + 1]);
+            op.i[ms][d] = th ? B::merge_hi(rawi[ms][2 * d], rawi[ms][2 * d + 1]) : B::merge_lo(rawi[ms][2 * d], rawi[ms][2 * d + 1]);
           }
         }
         A16 re, im;
@@ -610,20 +605,17 @@ struct Body {
             apply8(re, im, half, tr, ti);
           }
         }
+        if (th == 0) {
+          re0 = re; im0 = im;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
-          u32 vr = B::template pack<DT>(re[r], B::fconst(0.f));
-          u32 vi = B::template pack<DT>(im[r], B::fconst(0.f));
-          if (th == 1) {
+          for (int r = 0; r < 16; r++) {
+            if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
             const int c = (r & 3) + 8 * (r >> 2);
             const int s1 = c / GEO::N1, rwc = c % GEO::N1;
             i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
-            B::lds_w32(off, sre[r] | (vr << 16));
-            B::lds_w32(off + GEO::PLANE, sim[r] | (vi << 16));
-          } else {
-            sre[r] = vr & 0xffffu;
-            sim[r] = vi & 0xffffu;
+            B::lds_w32(off, B::template pack<DT>(re0[r], re[r]));
+            B::lds_w32(off + GEO::PLANE, B::template pack<DT>(im0[r], im[r]));
           }
         }
       }

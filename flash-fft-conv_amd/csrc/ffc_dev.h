@@ -186,6 +186,9 @@ struct DevB {
   // hide a value from LICM/CSE so per-phase address math is recomputed instead of kept live
   static FFC_FN i32 opaque(i32 x) { asm volatile("" : "+v"(x)); return x; }
   static FFC_FN u32 sel(pred p, u32 a, u32 b) { return p ? a : b; }
+  // 16-bit half merges in one v_perm_b32: (lo16(a) | lo16(b) << 16) and (hi16(a) | hi16(b) << 16)
+  static FFC_FN u32 merge_lo(u32 a, u32 b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }
+  static FFC_FN u32 merge_hi(u32 a, u32 b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
   static FFC_FN i32 imin(i32 a, int b) { return a < b ? a : b; }
   static FFC_FN u32 g_r16(const void* base, i32 e, pred p) {
     uint16_t v = 0;

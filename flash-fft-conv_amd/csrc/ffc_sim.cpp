@@ -192,6 +192,8 @@ struct SimB {
   static i32 opaque(const i32& x) { return x; }
   static u32 uconst(uint32_t c) { return u32(c); }
   static i32 imin(const i32& a, int b) { i32 r; for (int i = 0; i < 64; i++) r.v[i] = a.v[i] < b ? a.v[i] : b; return r; }
+  static u32 merge_lo(const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] & 0xffffu) | (b.v[i] << 16); return r; }
+  static u32 merge_hi(const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = (a.v[i] >> 16) | (b.v[i] & 0xffff0000u); return r; }
   static u32 sel(const pred& p, const u32& a, const u32& b) { u32 r; for (int i = 0; i < 64; i++) r.v[i] = p.v[i] ? a.v[i] : b.v[i]; return r; }
   static u32 g_r16(const void* base, const i32& e, const pred& p) {
     u32 r;
