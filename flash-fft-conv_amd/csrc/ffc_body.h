@@ -47,7 +47,23 @@ struct ConvArgs {
   int flags;             // reserved tuning flags
   int stream;            // 1: activation rows through non-temporal accesses (set by the host when every row is touched once)
   int persist;           // grid cap of the persistent one-wave-per-unit kernels (CU count rounded down to 8)
+  int R;                 // > 1: multi-pass size, fft size = R * GEO::N (HostPlan::R); 0 / 1: single pass
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
+};
+
+// One pass of a multi-pass size (fft size N = R * M, M = GEO::N = N1 * Mi; HostPlan::R).  With n = n0 M + n1 Mi + mi and
+// f = k0 + R f', pass k0 computes the M-point circular convolution of
+//   x_k0[n1 Mi + mi] = W_N^{(n1 Mi + mi) k0} * sum_n0 W_R^{n0 k0} z[n0 M + n1 Mi + mi]
+// with the kernel samples K[k0 + R f'], and the result is  y[n0 M + m] = (1/R) sum_k0 W_R^{-n0 k0} W_N^{-m k0} y_k0[m].
+// Inside the fused kernel this costs almost nothing: the factor W_{R N1}^{n1 k0} is folded into the outer digit's DFT
+// matrix (plan tables matk[k0]), the factor W_N^{mi k0} into the phase of the outer twiddle chain (k1 -> k0 + R k1 on an
+// N-point circle), the sum over n0 is a +-1 / +-i combination of input rows (absent when L <= M), and the sum over k0 is a
+// read-modify-write of the output rows by the same wave (absent for k0 = 0).  The reference reaches these sizes through
+// an extra HBM round trip (butterfly kernels, csrc/flashfftconv/butterfly/*).
+struct Pass {
+  int k0 = 0, R = 1;
+  const uint8_t* mat_fwd = nullptr;   // outer-digit operand tables of this pass (global memory)
+  const uint8_t* mat_inv = nullptr;
 };
 
 template <class B, class GEO, int DT>
@@ -122,8 +138,9 @@ struct Body {
   // Twiddle chain: t[i] = scale * cis(sign * 2*pi * ((base + off_i*step) mod N) / N) for the 8 row offsets
   // off = {0,1,2,3,8,9,10,11} an accumulator half holds: three v_sin/v_cos pairs (exact integer phases,
   // argument in revolutions) and seven complex multiplies instead of 8 sincos + per-element phase math.
-  static FFC_FN void cis_rev(i32 phase, float sign, f32* c, f32* s) {
-    f32 x = B::i2f(phase & (GEO::N - 1)) * (1.0f / (float)GEO::N);
+  // nmask / inv_n: the circle the phase lives on (N - 1, 1 / N); compile-time constants for the single-pass sizes
+  static FFC_FN void cis_rev(i32 phase, float sign, f32* c, f32* s, int nmask = GEO::N - 1, float inv_n = 1.0f / (float)GEO::N) {
+    f32 x = B::i2f(phase & nmask) * inv_n;
     f32 cc = B::cos_rev(x), ss = B::sin_rev(x);
     B::settle(cc, ss);     // see DevB::settle: transcendental results are fenced before packed-math consumers
     *c = cc;
@@ -145,11 +162,12 @@ struct Body {
   // Same chain with packed math: pairs of consecutive rows {0,1},{2,3},{8,9},{10,11}; t1 = t0 w, then the pairs
   // are stepped by w^2 and w^8 (two elements per packed instruction).
   using F2 = typename B::F2;
-  static FFC_FN void chain8p(i32 base, i32 step, float sign, float scale, F2 (&tr)[4], F2 (&ti)[4]) {
+  static FFC_FN void chain8p(i32 base, i32 step, float sign, float scale, F2 (&tr)[4], F2 (&ti)[4],
+                             int nmask = GEO::N - 1, float inv_n = 1.0f / (float)GEO::N) {
     f32 c0, s0, c1, s1, c8, s8;
-    cis_rev(base, sign, &c0, &s0);
-    cis_rev(step, sign, &c1, &s1);
-    cis_rev(step * 8, sign, &c8, &s8);
+    cis_rev(base, sign, &c0, &s0, nmask, inv_n);
+    cis_rev(step, sign, &c1, &s1, nmask, inv_n);
+    cis_rev(step * 8, sign, &c8, &s8, nmask, inv_n);
     c0 = c0 * scale; s0 = s0 * scale;
     f32 c2 = c1 * c1 - s1 * s1, s2 = (c1 + c1) * s1;
     tr[0] = B::f2(c0, c0 * c1 - s0 * s1);
@@ -259,6 +277,12 @@ struct Body {
   }
 
   struct Unit { int eb; int wq; };   // E base (bytes) of this wave's unit, wave index inside the unit
+  static FFC_FN Pass make_pass(const ConvArgs& a, int k0) {
+    Pass ps;
+    ps.k0 = k0; ps.R = a.R;
+    ps.mat_fwd = a.tab + a.t.matk[k0][0]; ps.mat_inv = a.tab + a.t.matk[k0][1];
+    return ps;
+  }
 
   // ------------------------------------------------------------------ global <-> E row copies
   // A unit's E holds ROWS rows of Mi points per plane.  OUTER: the rows are the n1 slices of one
@@ -460,13 +484,134 @@ struct Body {
     }
   }
 
+  // ------------------------------------------------------------------ multi-pass sizes: rows of pass k0 (see struct Pass)
+  // a + sb * b on packed dtype pairs, fp32 arithmetic, one rounding
+  static FFC_FN u32 add2(u32 a, u32 b, float sb) {
+    f32 lo = B::template unpack_lo<DT>(a) + B::template unpack_lo<DT>(b) * sb;
+    f32 hi = B::template unpack_hi<DT>(a) + B::template unpack_hi<DT>(b) * sb;
+    return B::template pack<DT>(lo, hi);
+  }
+  static FFC_FN U4 add4(const U4& a, const U4& b, float sb) {
+    U4 o; o.x = add2(a.x, b.x, sb); o.y = add2(a.y, b.y, sb); o.z = add2(a.z, b.z, sb); o.w = add2(a.w, b.w, sb);
+    return o;
+  }
+  static FFC_FN U4 mul4(const U4& v, const U4& g) {
+    U4 o; o.x = mul2(v.x, g.x); o.y = mul2(v.y, g.y); o.z = mul2(v.z, g.z); o.w = mul2(v.w, g.w);
+    return o;
+  }
+  static FFC_FN U4 mask4(const U4& v, pred ok) {
+    U4 o; o.x = B::sel(ok, v.x, B::uconst(0)); o.y = B::sel(ok, v.y, B::uconst(0));
+    o.z = B::sel(ok, v.z, B::uconst(0)); o.w = B::sel(ok, v.w, B::uconst(0));
+    return o;
+  }
+  // (u * pregate)[n .. n+7] of batch row b, zero beyond L / for a missing row
+  static FFC_FN U4 load_gated(const ConvArgs& a, int h, int b, i32 n, int fast) {
+    const bool ok = b < a.B;
+    const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+    U4 v = gload8((const uint16_t*)a.u + ro, n, a.L, fast, ok);
+    if (fast) v = mask4(v, (n < a.L) && ok);
+    if (a.pregate) v = mul4(v, gload8((const uint16_t*)a.pregate + ro, n, a.L, fast, ok));
+    return v;
+  }
+  // rows_in of pass k0: E row n1 = sum_n0 W_R^{n0 k0} (u * pregate)[n0 M + n1 Mi + m]; plane 0 = Re (batch row 2p),
+  // plane 1 = Im (row 2p+1).  W_R^{q'} = (-i)^q with q = q' * 4 / R:  (-i)^q (r + i s) = (r,s), (s,-r), (-r,-s), (-s,r).
+  template <int NC>
+  static FFC_FN void rows_in_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    const i32 lane = B::opaque(B::lane());
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
+    const int n0max = (a.L + GEO::N - 1) / GEO::N;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
+      pred sw;
+      i32 off = pair_off(row, m, &sw) + un.eb;
+      i32 n = row * GEO::Mi + m;
+      U4 acc[2];
+      acc[0] = load_gated(a, h, 2 * pq, n, fast);
+      acc[1] = load_gated(a, h, 2 * pq + 1, n, fast);
+#pragma unroll 1
+      for (int n0 = 1; n0 < n0max; n0++) {
+        U4 w0 = load_gated(a, h, 2 * pq, n + n0 * GEO::N, fast), w1 = load_gated(a, h, 2 * pq + 1, n + n0 * GEO::N, fast);
+        const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
+        const float sgr = q < 2 ? 1.0f : -1.0f, sgi = (q == 0 || q == 3) ? 1.0f : -1.0f;
+        if (q & 1) { acc[0] = add4(acc[0], w1, sgr); acc[1] = add4(acc[1], w0, sgi); }
+        else { acc[0] = add4(acc[0], w0, sgr); acc[1] = add4(acc[1], w1, sgi); }
+      }
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        const U4& v = acc[pl];
+        U4 o;
+        o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
+        o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
+        B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+      }
+    }
+  }
+  // rows_out of pass k0: y[n0 M + m] (+)= i^q y_k0[m] (* postgate), q = n0 k0 4/R: i^q (r + i s) = (r,s), (-s,r), (-r,-s),
+  // (s,-r).  Passes k0 > 0 add to what the SAME wave stored in the earlier passes (its own column slice).
+  template <int NC>
+  static FFC_FN void rows_out_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    const i32 lane = B::opaque(B::lane());
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
+    const int n0max = (a.L + GEO::N - 1) / GEO::N;
+    int64_t ro[2]; bool okb[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+      okb[pl] = (2 * pq + pl) < a.B;
+      ro[pl] = ((int64_t)(okb[pl] ? 2 * pq + pl : 0) * a.H + h) * a.L;
+    }
+#pragma unroll 1
+    for (int n0 = 0; n0 < n0max; n0++) {
+      const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
+      // the earlier passes' sums of this block: all requested up front (a load behind each store would wait out its
+      // latency chunk by chunk: loads may not pass the stores to the same tensor)
+      // (not in the backward kernels: 64 more registers do not fit their 128-VGPR budget)
+      constexpr bool HOIST = !B::LEAN_OUTER;
+      RowRegsT<HOIST ? NC : 1> old;
+      if (HOIST && ps.k0 > 0) {
+#pragma unroll
+        for (int i = 0; i < NC; i++) {
+          i32 idx = lane + i * 64;
+          i32 n = (idx / CPR) * GEO::Mi + (idx % CPR) * 8 + un.wq * 128 * GEO::S1 + n0 * GEO::N;
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++) old.v[i][pl] = gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NC; i++) {
+        i32 idx = lane + i * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
+        pred sw;
+        i32 off = pair_off(row, m, &sw) + un.eb;
+        U4 y[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          U4 o = B::lds_r128(off + pl * GEO::PLANE);
+          y[pl].x = B::sel(sw, o.z, o.x); y[pl].y = B::sel(sw, o.w, o.y);
+          y[pl].z = B::sel(sw, o.x, o.z); y[pl].w = B::sel(sw, o.y, o.w);
+        }
+        i32 n = row * GEO::Mi + m + n0 * GEO::N;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          // plane 0: {r, -s, -r, s}[q], plane 1: {s, r, -s, -r}[q]
+          U4 c = ((q & 1) != 0) == (pl == 0) ? y[1] : y[0];
+          const float sg = pl == 0 ? ((q == 0 || q == 3) ? 1.0f : -1.0f) : (q < 2 ? 1.0f : -1.0f);
+          if (a.postgate) c = mul4(c, gload8((const uint16_t*)a.postgate + ro[pl], n, a.L, fast, okb[pl]));
+          if (ps.k0 > 0) c = add4(HOIST ? old.v[HOIST ? i : 0][pl] : gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]), c, sg);
+          gstore8((uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl], c);
+        }
+      }
+    }
+  }
+
   // ------------------------------------------------------------------ phases A / C (outer DFT, in place)
   // The wave owns columns [wq*128*S1, +128*S1) of every E row: 4 tiles t, lane j <-> column
   // s1*128 + 4j + t.  FWD: rows are n1 (real pair x), result rows k1 with the W_N^{m k1} twiddle.
   // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
   // HALF: input rows n1 >= 16 are all zero (L <= 16*Mi, 32-point outer digit) -> one K-step.
-  template <bool FWD, bool HALF>
-  static FFC_FN void outer_stage_tile(int L, Unit un, float s_fwd = 1.0f) {
+  template <bool FWD, bool HALF, bool RP = false>
+  static FFC_FN void outer_stage_tile(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
@@ -479,7 +624,8 @@ struct Body {
     for (int s = 0; s < GEO::S1; s++)
       colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
     Mat F1;
-    lds_mat(F1, GEO::L_F1);
+    if constexpr (RP) load_mat(F1, FWD ? ps.mat_fwd : ps.mat_inv, lane);   // this pass's table (6 KB, L2-resident)
+    else lds_mat(F1, GEO::L_F1);
 #pragma unroll 1
     for (int t = 0; t < 4; t++) {          // the 4 column tiles of this wave; a runtime loop bounds the live ranges
       // operand halves come straight from 16-bit LDS reads (element t of each 8-byte chunk) and the results go
@@ -500,12 +646,8 @@ struct Body {
             const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
             const int s1 = c / GEO::N1, rwc = c % GEO::N1;
             i32 off = colt[s1] + rwc * (GEO::Mi * 2);
+            // no length mask: rows_store zero-fills every E row this stage reads (HALF never reads rows >= 16)
             vr[hf] = B::lds_r16(off); vi[hf] = B::lds_r16(off + GEO::PLANE);
-            if (FWD) {
-              pred ok = ((hi * 4 + rwc) * GEO::Mi) < L;
-              vr[hf] = B::sel(ok, vr[hf], B::uconst(0));
-              vi[hf] = B::sel(ok, vi[hf], B::uconst(0));
-            }
           }
           op.r[ms][d] = vr[0] | (vr[1] << 16);
           op.i[ms][d] = vi[0] | (vi[1] << 16);
@@ -522,7 +664,8 @@ struct Body {
           i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + t);
           i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
           F2 tr[4], ti[4];
-          chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
+          if constexpr (RP) chain8p(m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, tr, ti, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+          else chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
           apply8(re, im, half, tr, ti);
         }
       }
@@ -548,8 +691,8 @@ struct Body {
   // (B::merge_lo / merge_hi = v_perm_b32), and the results go back as one v_cvt_pk(tile 2tp, tile 2tp+1) per row and plane
   // (the first tile's fp32 accumulators wait for the second tile's instead of a stash of packed halves).
   // No length masks: every E row this stage reads was written by rows_store, zero beyond L (HALF never reads rows >= 16).
-  template <bool FWD, bool HALF>
-  static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f) {
+  template <bool FWD, bool HALF, bool RP = false>
+  static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
@@ -562,7 +705,8 @@ struct Body {
     for (int s = 0; s < GEO::S1; s++)
       colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
     Mat F1;
-    lds_mat(F1, GEO::L_F1);
+    if constexpr (RP) load_mat(F1, FWD ? ps.mat_fwd : ps.mat_inv, lane);   // this pass's table (6 KB, L2-resident)
+    else lds_mat(F1, GEO::L_F1);
 #pragma unroll 1
     for (int tp = 0; tp < 2; tp++) {       // tiles (2tp, 2tp+1): a runtime loop bounds the live ranges
       u32 rawr[2][8], rawi[2][8];
@@ -601,7 +745,8 @@ struct Body {
             i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + 2 * tp + th);
             i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
             F2 tr[4], ti[4];
-            chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
+            if constexpr (RP) chain8p(m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, tr, ti, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+            else chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
             apply8(re, im, half, tr, ti);
           }
         }
@@ -624,10 +769,10 @@ struct Body {
 
   // The forward/dx kernels take the tile-pair variant (fastest); the backward kernels, which run on the
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
-  template <bool FWD, bool HALF>
-  static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f) {
-    if constexpr (B::LEAN_OUTER) outer_stage_tile<FWD, HALF>(L, un, s_fwd);
-    else outer_stage_pair<FWD, HALF>(L, un, s_fwd);
+  template <bool FWD, bool HALF, bool RP = false>
+  static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
+    if constexpr (B::LEAN_OUTER) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
+    else outer_stage_pair<FWD, HALF, RP>(L, un, s_fwd, ps);
   }
 
   // ------------------------------------------------------------------ phase B (inner tile)
@@ -724,8 +869,8 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  template <bool TWR = true>
-  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0) {
+  template <bool TWR = true, bool RP = false>
+  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     Op op;
@@ -774,7 +919,13 @@ struct Body {
         i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
         i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
         F2 tr[4], ti[4];
-        chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);     // conj(W^{m k1}) = cos + i sin
+        // conj(W^{m k1}) = cos + i sin; multi-pass: k1 -> k0 + R k1 on the N-point circle
+        if constexpr (RP) {
+          i32 kk = k1 * ps.R + ps.k0;
+          chain8p(B::mul24(mlane + n30, kk), kk, 1.0f, s_inv, tr, ti, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+        } else {
+          chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
+        }
         apply8(re, im, half, tr, ti);
       }
     }
@@ -842,7 +993,8 @@ struct Body {
     k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
     cmul(re, im, k);
   }
-  static FFC_FN void oi_twiddle(float s_inv, int tau, A16& re, A16& im) {
+  template <bool RP = false>
+  static FFC_FN void oi_twiddle(float s_inv, int tau, A16& re, A16& im, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
@@ -852,7 +1004,12 @@ struct Body {
       i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
       i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
       F2 tr[4], ti[4];
-      chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
+      if constexpr (RP) {
+        i32 kk = k1 * ps.R + ps.k0;
+        chain8p(B::mul24(mlane + n30, kk), kk, 1.0f, s_inv, tr, ti, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+      } else {
+        chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, s_inv, tr, ti);
+      }
       apply8(re, im, half, tr, ti);
     }
   }
@@ -869,7 +1026,8 @@ struct Body {
       B::lds_w64(off + GEO::PLANE, vi);
     }
   }
-  static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un) {
+  template <bool RP = false>
+  static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un, Pass ps = Pass()) {
     static_assert(GEO::N3 == GEO::N2 && GEO::OUTER, "inner_tile2: fused sizes with one inner matrix");
     const int tauB = tauA + 1;
     KfRegs kfA, kfB;
@@ -906,9 +1064,9 @@ struct Body {
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<true, true>(reB, imB, opB, R.F2);
     // outer inverse twiddle + write back
-    oi_twiddle(a.s_inv, tauA, reA, imA);
+    oi_twiddle<RP>(a.s_inv, tauA, reA, imA, ps);
     tile_store(tauA, R, reA, imA);
-    oi_twiddle(a.s_inv, tauB, reB, imB);
+    oi_twiddle<RP>(a.s_inv, tauB, reB, imB, ps);
     tile_store(tauB, R, reB, imB);
   }
 
@@ -923,7 +1081,7 @@ struct Body {
     if constexpr (GEO::NW > 1) B::barrier();
     else B::lds_fence();
   }
-  template <bool HALF, bool PROF = false>
+  template <bool HALF, bool PROF = false, bool RP = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
     // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
@@ -933,23 +1091,32 @@ struct Body {
     // the stores.  Requesting them any earlier (before phase B) costs more than it gains: the k_f loads of
     // phase B retire in order behind them and the tile loop has no registers to spare
     // (profiles/r01_phase_cycles.txt).
-    constexpr bool PREFETCH = HALF;    // full-length rows: 64 row registers on top of phase C would spill
-    const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
+    constexpr bool PREFETCH = HALF && !RP;    // full-length rows: 64 row registers on top of phase C would spill
+    // multi-pass sizes: the R passes of a pair run back to back (pair-major), so that the second read of the input rows and
+    // the read-modify-write of the output rows find them in L2
+    const int npass = RP ? a.R : 1;
+    const int iters = ((p1 - p0 + GEO::UPW - 1) / GEO::UPW) * npass;
     RowRegsT<NC> X;
     if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
-      const int p = p0 + it * GEO::UPW + u;
+      const int p = p0 + (RP ? it / npass : it) * GEO::UPW + u;
+      const Pass ps = RP ? make_pass(a, it % npass) : Pass();
+      const int hk = RP ? h * ps.R + ps.k0 : h;      // k_f row of this (head, pass)
       const bool act = p < p1;
       if (PROF) t0 = B::clock();
       if (act) {
-        if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
-        rows_store<NC>(a, h, p, un, X);
+        if constexpr (RP) {
+          rows_in_rp<NC>(a, h, p, un, ps);
+        } else {
+          if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
+          rows_store<NC>(a, h, p, un, X);
+        }
         B::lds_fence();
         FFC_TICK(0)
-        outer_stage<true, HALF>(a.L, un, a.s_fwd);
+        outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         FFC_TICK(1)
       }
       unit_barrier();
@@ -961,7 +1128,7 @@ struct Body {
         load_inner(R, un);
         if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2(a, h, un.wq * GEO::TPW + tt, R, un);
+          for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2<RP>(a, hk, un.wq * GEO::TPW + tt, R, un, ps);
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);
@@ -979,10 +1146,11 @@ struct Body {
       FFC_TICK(4)
       if (PREFETCH && it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
       if (act) {
-        outer_stage<false, HALF>(a.L, un);
+        outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
         B::lds_fence();
         FFC_TICK(5)
-        rows_out<NC>(a, h, p, un);
+        if constexpr (RP) rows_out_rp<NC>(a, h, p, un, ps);
+        else rows_out<NC>(a, h, p, un);
         FFC_TICK(6)
       }
     }
@@ -1003,8 +1171,8 @@ struct Body {
     setup_tables(a.tab, a.t);
     conv_job<HALF>(a, h, chunk);
   }
-  // one (head, chunk) job; the tables are already in LDS
-  template <bool HALF = false>
+  // one (head, chunk) job; the tables are already in LDS.  RP: all passes of a multi-pass size
+  template <bool HALF = false, bool RP = false>
   static FFC_FN void conv_job(const ConvArgs& a, int h, int chunk) {
     const int wv = B::wave();
     Unit un;
@@ -1015,7 +1183,7 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      outer_jobs<HALF && GEO::S1 == 1>(a, h, p0, p1, u, un);
+      outer_jobs<HALF && GEO::S1 == 1, false, RP>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -281,7 +281,14 @@ __device__ __forceinline__ bool map_block(int H, int nchunk, int* h, int* chunk)
 // invariants there would overflow into the accumulation registers that hold the dk_f partial sums.
 struct DevBO : DevB {
   static constexpr bool LEAN_OUTER = true;     // per-tile outer stages (fewer registers)
-  static FFC_FN i32 lane() { int x = (int)(threadIdx.x & 63); asm volatile("" : "+v"(x)); return x; }
+  // lane id from the execution mask (v_mbcnt: every call site runs with all 64 lanes active) instead of threadIdx.x, so
+  // that the work-item id register does not stay live for the whole kernel (under the 128-VGPR budget the allocator
+  // parked it in a0 across the pass loop of the multi-pass kernels; build.py check_agpr caught it)
+  static FFC_FN i32 lane() {
+    int x = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(x));
+    return x;
+  }
 };
 
 }  // namespace ffc
@@ -333,6 +340,8 @@ static int ffc_dispatch(int N, int dtype, A&&... args) {
     FFC_CASE(8192, 32, 16, 16)
     FFC_CASE(16384, 16, 32, 32)
     FFC_CASE(32768, 32, 32, 32)
+    FFC_CASE(65536, 32, 32, 32)        // multi-pass sizes: R passes of the 32768 kernel (HostPlan::R, struct Pass)
+    FFC_CASE(131072, 32, 32, 32)
   }
 #undef FFC_CASE
   return ffc_fail("unsupported fft size");

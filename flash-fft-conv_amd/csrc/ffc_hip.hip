@@ -79,7 +79,7 @@ int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
   ffc_plan* p = new ffc_plan();
   if (!build_plan((int)fft_size, dtype, &p->hp)) {
     delete p;
-    return fail("unsupported fft_size/dtype (supported: 256,512,1024,4096,8192,16384,32768; bf16/fp16)");
+    return fail("unsupported fft_size/dtype (supported: 256,512,1024,4096,8192,16384,32768,65536,131072; bf16/fp16)");
   }
   hipError_t e = hipMalloc((void**)&p->d_blob, p->hp.blob.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_blob, p->hp.blob.data(), p->hp.blob.size(), hipMemcpyHostToDevice);
@@ -114,7 +114,7 @@ void ffc_plan_destroy(ffc_plan* p) {
   delete p;
 }
 
-int64_t ffc_plan_kf_elems(const ffc_plan* p) { return p ? (int64_t)p->hp.NT * 1024 : 0; }
+int64_t ffc_plan_kf_elems(const ffc_plan* p) { return p ? (int64_t)p->hp.R * p->hp.NT * 1024 : 0; }
 double ffc_plan_kf_scale(const ffc_plan* p) { return p ? p->hp.s_k : 0; }
 int ffc_plan_kf_index(const ffc_plan* p, int32_t* out) {
   if (!p || !out) return fail("null arg");
@@ -124,7 +124,7 @@ int ffc_plan_kf_index(const ffc_plan* p, int32_t* out) {
 
 int ffc_kf_pack(const ffc_plan* p, const void* src, int64_t H, void* dst, void* stream) {
   if (!p || !src || !dst) return fail("null arg");
-  int per_h = p->hp.NT * 1024;
+  int per_h = p->hp.R * p->hp.NT * 1024;
   dim3 grid((per_h + 255) / 256, (unsigned)H), block(256);
   if (p->hp.dtype == DT_BF16)
     hipLaunchKernelGGL(kf_pack_kernel<DT_BF16>, grid, block, 0, (hipStream_t)stream, (const float2*)src, p->d_freq,

@@ -27,11 +27,39 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
   }
 }
 
+// multi-pass sizes (fft 65536 / 131072): the R passes of a (head, chunk) job run one after the other in the same workgroup,
+// so that the read-modify-write of the output rows stays inside one wave (struct Pass, Body::rows_out_rp)
+template <class GEO, int DT, bool HALF>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_rp_kernel(ConvArgs a) {
+  using BD = Body<DevB, GEO, DT>;
+  int h, chunk;
+  if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
+  BD::setup_tables(a.tab, a.t);
+  BD::template conv_job<HALF, true>(a, h, chunk);
+}
+
 template <class GEO, int DT>
 struct ConvLaunch {
   static int run(const ConvArgs& a, hipStream_t st) {
     int hpad = (a.H + 7) & ~7;
     int grid = hpad * a.nchunk;
+    if (a.R > 1) {
+      if constexpr (GEO::N == 32768) {
+        if (16 * GEO::Mi >= a.L) {
+          static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        } else {
+          static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
+      } else {
+        return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
+      }
+    }
     if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
     if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= a.L) {
@@ -65,7 +93,9 @@ extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, co
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = ffc_persist(p);
-  a.stream = p->env_stream >= 0 ? p->env_stream : 1;     // every row is read / written exactly once per launch
+  a.R = p->hp.R;
+  // every row is read / written exactly once per launch (multi-pass sizes re-read the rows in every pass: plain accesses)
+  a.stream = p->env_stream >= 0 ? p->env_stream : (p->hp.R > 1 ? 0 : 1);
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }
 

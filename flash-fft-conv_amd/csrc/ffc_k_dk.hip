@@ -33,6 +33,7 @@ extern "C" int ffc_kernel_ifft_grad_slabs(const ffc_plan* p, const void* slabs, 
   a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
   a.flags = p->env_flags;
+  a.R = p->hp.R;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }
 
@@ -48,13 +49,14 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
   a.scale = (float)(1.0 / p->hp.s_fwd); a.s_inv = (float)p->hp_bf.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
   a.flags = p->env_flags;
+  a.R = p->hp.R;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }
 
 // complex output (pair-plane tensor (2, H, N) bf16) instead of dk: first step of dk for big FFT sizes
 extern "C" int ffc_kernel_ifft_grad_c(const ffc_plan* p, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream) {
   if (!p || !ws || !outpair) return ffc_fail("null arg");
-  if (p->hp.N1 <= 1) return ffc_fail("ffc_kernel_ifft_grad_c: inner size must be >= 4096");
+  if (p->hp.N1 <= 1 || p->hp.R > 1) return ffc_fail("ffc_kernel_ifft_grad_c: inner size must be one of 4096 .. 32768");
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   DkArgs a{};

@@ -26,11 +26,48 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void dkf_kernel_small(DkfArgs d) 
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
   Modes<DevB, GEO, DT>::template dkf<false>(d, h, chunk, blockIdx.x);
 }
+// multi-pass sizes: the R passes of a (head, chunk) job run one after the other in the same workgroup (see conv_rp_kernel)
+template <class GEO, int DT, bool HALF>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void dkf_rp_kernel(DkfArgs d) {
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
+  const int wv = DevBO::wave(), wg = blockIdx.x;
+#pragma unroll 1
+  for (int k0 = 0; k0 < d.c.R; k0++) Modes<DevBO, GEO, DT>::template dkf<HALF, true>(d, h, chunk, wg, k0, wv);
+}
+template <class GEO, int DT, bool HALF>
+__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_rp_kernel(DkfArgs d) {
+  int h, chunk;
+  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+  Modes<DevBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
+  const int wv = DevBO::wave(), wg = blockIdx.x;
+#pragma unroll 1
+  for (int k0 = 0; k0 < d.c.R; k0++) Modes<DevBO, GEO, DT>::template bwd<HALF, true>(d, h, chunk, wg, k0, wv);
+}
 template <class GEO, int DT>
 struct DkfLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
     int ngrid = hpad * d.c.nchunk;
+    if (d.c.R > 1) {
+      if constexpr (GEO::N == 32768) {
+        const dim3 grid(ngrid), block(GEO::WGW * 64);
+        if (16 * GEO::Mi >= d.c.L) {
+          static int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((dkf_rp_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
+        } else {
+          static int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((dkf_rp_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("dkf_rp_kernel launch: ") + hipGetErrorString(e));
+      } else {
+        return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
+      }
+    }
     if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
     const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
@@ -84,6 +121,24 @@ struct BwdLaunch {
   static int run(const DkfArgs& d, hipStream_t st) {
     int hpad = (d.c.H + 7) & ~7;
     int ngrid = hpad * d.c.nchunk;
+    if (d.c.R > 1) {
+      if constexpr (GEO::N == 32768) {
+        const dim3 grid(ngrid), block(GEO::WGW * 64);
+        if (16 * GEO::Mi >= d.c.L) {
+          static int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
+        } else {
+          static int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_rp_kernel launch: ") + hipGetErrorString(e));
+      } else {
+        return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
+      }
+    }
     if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
     const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
@@ -115,10 +170,10 @@ extern "C" int64_t ffc_dkf_workspace_bytes(const ffc_plan* p, int64_t B, int64_t
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   int upw = 8 / p->hp.NW;
-  int64_t slabs = (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.NT * 2048 * 4;
-  // + spectrum scratch: one N-point dtype-complex slot per (workgroup, unit) of the grid
+  int64_t slabs = (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.R * p->hp.NT * 2048 * 4;   // rows (head, pass)
+  // + spectrum scratch: one dtype-complex slot of the fused kernel's size per (workgroup, unit) of the grid
   int64_t hpad = (H + 7) & ~(int64_t)7;
-  int64_t zs = p->hp.N1 > 1 ? hpad * nchunk * upw * (int64_t)p->hp.N * 4 : 0;
+  int64_t zs = p->hp.N1 > 1 ? hpad * nchunk * upw * (int64_t)(p->hp.N / p->hp.R) * 4 : 0;
   return slabs + zs;
 }
 // number of fp32 partial-sum slabs [slab][H][kf_elems][2] at the start of the workspace (k_f's internal order)
@@ -129,7 +184,7 @@ extern "C" int64_t ffc_dkf_slab_count(const ffc_plan* p, int64_t B, int64_t H) {
   return (int64_t)nchunk * ffc_slabs_per_chunk(p);
 }
 static void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk) {
-  return (uint8_t*)ws + (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.NT * 2048 * 4;
+  return (uint8_t*)ws + (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.R * p->hp.NT * 2048 * 4;
 }
 
 extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void* u, const void* pregate, const void* postgate,
@@ -145,7 +200,8 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   a.persist = ffc_persist(p);
-  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate) ? 1 : 0);    // see Body::STREAM_ROWS
+  a.R = p->hp.R;
+  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate && p->hp.R == 1) ? 1 : 0);    // see Body::STREAM_ROWS
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   return ffc_dispatch<DkfLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
@@ -179,7 +235,8 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   a.persist = ffc_persist(p);
-  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate) ? 1 : 0);    // see Body::STREAM_ROWS
+  a.R = p->hp.R;
+  a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate && p->hp.R == 1) ? 1 : 0);    // see Body::STREAM_ROWS
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   d.dpost = p->hp.N1 > 1 ? dpost : nullptr;

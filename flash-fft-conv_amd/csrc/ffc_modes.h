@@ -24,6 +24,7 @@ struct KfArgs {
                        // its scaled spectrum would otherwise fall into the fp16 subnormal range)
   const void* xpair;   // optional complex input instead of k: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;            // Lk % 4 == 0 and 16-byte aligned
+  int R;               // > 1: multi-pass size (struct Pass); k_f rows are (head, pass)
 };
 
 struct DkfArgs {
@@ -53,6 +54,7 @@ struct DkArgs {
   int flags;           // debugging switches
   void* outpair;       // optional complex output instead of dk: pair-plane tensor (2, H, M) dtype (big FFT sizes)
   int fast;
+  int R;               // > 1: multi-pass size (struct Pass); slab rows are (head, pass)
 };
 
 #ifndef FFC_WREG
@@ -72,6 +74,11 @@ struct Modes : Body<B, GEO, DT> {
   using Unit = typename BD::Unit;
   using Op = typename BD::Op;
   using InnerRegs = typename BD::InnerRegs;
+  static FFC_FN Pass make_pass(const uint8_t* tab, const PlanTabs& t, int R, int k0) {
+    Pass ps;
+    ps.k0 = k0; ps.R = R; ps.mat_fwd = tab + t.matk[k0][0]; ps.mat_inv = tab + t.matk[k0][1];
+    return ps;
+  }
 
   // ------------------------------------------------------------------ k -> k_f
   // 8 fp32 starting at element e0 (per lane) of base, zero beyond `lim` (per lane limit on e0+i)
@@ -111,7 +118,45 @@ struct Modes : Body<B, GEO, DT> {
       B::lds_w128(off + GEO::PLANE, z, B::ptrue());
     }
   }
-  static FFC_FN void kf_store(const KfArgs& a, int unit_id, int tau, const A16& re, const A16& im) {
+  // multi-pass sizes: E row n1 = sum_n0 W_R^{n0 k0} k[n0 M + n1 Mi + m] (fp32 sums; (-i)^q (w + 0i) = (w,0),(0,-w),(-w,0),(0,w))
+  static FFC_FN void k_rows_in_rp(const KfArgs& a, int unit_id, Unit un, Pass ps) {
+    const i32 lane = B::opaque(B::lane());
+    const int n0max = (a.Lk + GEO::N - 1) / GEO::N;
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + un.wq * 128 * GEO::S1;
+      pred sw;
+      i32 off = BD::pair_off(row, m, &sw) + un.eb;
+      i32 hd = row * 0 + unit_id, n = row * GEO::Mi + m;
+      pred ok = hd < a.H;
+      f32 vr[8], vi[8];
+#pragma unroll
+      for (int q8 = 0; q8 < 8; q8++) { vr[q8] = B::fconst(0.f); vi[q8] = B::fconst(0.f); }
+#pragma unroll 1
+      for (int n0 = 0; n0 < n0max; n0++) {
+        f32 w[8];
+        fload8(a.k, hd * a.Lk + n + n0 * GEO::N, n + n0 * GEO::N, a.Lk, a.fast != 0, ok, w);
+        const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
+        const float s = (q == 0 || q == 3) ? a.prescale : -a.prescale;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) {
+          if (q & 1) vi[q8] = vi[q8] + w[q8] * s;
+          else vr[q8] = vr[q8] + w[q8] * s;
+        }
+      }
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        const f32* v = pl ? vi : vr;
+        u32 p0 = B::template pack<DT>(v[0], v[1]), p1 = B::template pack<DT>(v[2], v[3]);
+        u32 p2 = B::template pack<DT>(v[4], v[5]), p3 = B::template pack<DT>(v[6], v[7]);
+        U4 o;
+        o.x = B::sel(sw, p2, p0); o.y = B::sel(sw, p3, p1); o.z = B::sel(sw, p0, p2); o.w = B::sel(sw, p1, p3);
+        B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+      }
+    }
+  }
+  static FFC_FN void kf_store(const KfArgs& a, int unit_id, int tau, const A16& re, const A16& im, int hmul = 1) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -122,7 +167,7 @@ struct Modes : Body<B, GEO, DT> {
       for (int q = 0; q < 4; q++) w[q] = B::template pack<DT>(re[4 * rq + q] * a.scale, im[4 * rq + q] * a.scale);
       v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
       if constexpr (GEO::OUTER) {
-        pred ok = (c * 0 + unit_id) < a.H;
+        pred ok = (c * 0 + unit_id) < a.H * hmul;      // hmul: rows are (head, pass) for the multi-pass sizes
         i32 idx = ((hi + (tau * 8 + 2 * rq)) * 32 + c) + unit_id * (GEO::NT * 256);
         B::g_w128(a.kf, idx, v, ok);
       } else {
@@ -155,6 +200,30 @@ struct Modes : Body<B, GEO, DT> {
     const bool act = unit_id < nunits;
     InnerRegs R;
     BD::load_inner(R, un);
+    if constexpr (GEO::N == 32768) {
+      if (a.R > 1) {       // multi-pass size: k_f rows (head, k0) = the spectrum samples f = k0 (mod R)
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.R; k0++) {
+          const Pass ps = make_pass(a.tab, a.t, a.R, k0);
+          if (act) {
+            k_rows_in_rp(a, unit_id, un, ps);
+            B::lds_fence();
+            BD::template outer_stage<true, false, true>(a.Lk, un, a.s_fwd, ps);
+          }
+          B::barrier();
+          if (act) {
+#pragma unroll 1
+            for (int tt = 0; tt < GEO::TPW; tt++) {
+              A16 re, im;
+              BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+              kf_store(a, unit_id * a.R + k0, un.wq * GEO::TPW + tt, re, im, a.R);
+            }
+          }
+          B::barrier();
+        }
+        return;
+      }
+    }
     if constexpr (GEO::OUTER) {
       if (act) {
         if (a.xpair) {
@@ -459,8 +528,9 @@ struct Modes : Body<B, GEO, DT> {
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
   // accumulator registers are addressed statically.
-  template <bool WITH_DX>
-  static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W) {
+  template <bool WITH_DX, bool RP = false>
+  static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W,
+                               Pass ps = Pass()) {
 #pragma unroll 1
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
@@ -485,15 +555,19 @@ struct Modes : Body<B, GEO, DT> {
       }
       if constexpr (WITH_DX) {
         kf_conj_mul(kf, re, im);
-        BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
+        BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
       }
     }
   }
-  template <bool HALF = false>
-  static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear) {
+  template <bool HALF = false, bool RP = false>
+  static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear, int k0 = 0, int wv_in = 0) {
     const ConvArgs& a = d.c;
-    BD::setup_tables(a.tab, a.t);
-    const int wv = B::wave();
+    const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
+    constexpr int NCX = (HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH;
+    // multi-pass kernels copy the tables and read the wave index once, before their pass loop (nothing derived from the
+    // work-item id stays live across the passes: on the 128-VGPR budget it would be parked in an accumulation register)
+    if constexpr (!RP) BD::setup_tables(a.tab, a.t);
+    const int wv = RP ? wv_in : B::wave();
     Unit un;
     un.wq = wv % GEO::NW;
     const int u = wv / GEO::NW;
@@ -504,8 +578,10 @@ struct Modes : Body<B, GEO, DT> {
     ConvArgs av = a;            // v = u * pregate
     ConvArgs ad = a;            // dc = dout * postgate
     ad.u = d.dout; ad.pregate = a.postgate;
-    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit)
-    float* slab = d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
+    // Multi-pass sizes: slab rows are (head, pass).
+    float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
+                     : d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -517,9 +593,10 @@ struct Modes : Body<B, GEO, DT> {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
         if (act) {
-          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(av, h, p, un);
+          if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
+          else BD::template rows_in<NCX>(av, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -533,14 +610,15 @@ struct Modes : Body<B, GEO, DT> {
         }
         BD::unit_barrier();
         if (act) {
-          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
+          if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
+          else BD::template rows_in<NCX>(ad, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<false>(a, h, un, R, zs, slab, it == 0, W);
+          bwd_tiles<false, RP>(a, h, un, R, zs, slab, it == 0, W, ps);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
@@ -612,11 +690,16 @@ struct Modes : Body<B, GEO, DT> {
     }
     BD::cmul_conj(re, im, k);
   }
-  template <bool HALF = false>
-  static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear) {
+  template <bool HALF = false, bool RP = false>
+  static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear, int k0 = 0, int wv_in = 0) {
     const ConvArgs& a = d.c;
-    BD::setup_tables(a.tab, a.t);
-    const int wv = B::wave();
+    const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
+    const int hk = RP ? h * a.R + k0 : h;          // k_f row of this (head, pass)
+    constexpr int NCX = (HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH;
+    // multi-pass kernels copy the tables and read the wave index once, before their pass loop (nothing derived from the
+    // work-item id stays live across the passes: on the 128-VGPR budget it would be parked in an accumulation register)
+    if constexpr (!RP) BD::setup_tables(a.tab, a.t);
+    const int wv = RP ? wv_in : B::wave();
     Unit un;
     un.wq = wv % GEO::NW;
     const int u = wv / GEO::NW;
@@ -633,8 +716,10 @@ struct Modes : Body<B, GEO, DT> {
     ap.y = d.dpre; ap.postgate = a.u;
     ConvArgs aq = a;            // dpost = conv(u*pregate, k) * dout
     aq.y = d.dpost; aq.postgate = d.dout;
-    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit)
-    float* slab = d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+    // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
+    // Multi-pass sizes: slab rows are (head, pass).
+    float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
+                     : d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -648,9 +733,10 @@ struct Modes : Body<B, GEO, DT> {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
         if (act) {
-          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(av, h, p, un);
+          if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
+          else BD::template rows_in<NCX>(av, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -664,41 +750,48 @@ struct Modes : Body<B, GEO, DT> {
             if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
               // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
               typename BD::KfRegs kf;
-              BD::load_kf(a, h, tau, kf);
+              BD::load_kf(a, hk, tau, kf);
               kf_plain_mul(kf, re, im);
-              BD::template tile_inv<false>(a.s_inv, tau, R, un, re, im);
+              BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
             }
           }
         }
         BD::unit_barrier();
         if (d.dpost) {
           if (act) {
-            BD::template outer_stage<false, HALF && GEO::S1 == 1>(a.L, un);
+            BD::template outer_stage<false, HALF && GEO::S1 == 1, RP>(a.L, un, 1.0f, ps);
             B::lds_fence();
-            BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(aq, h, p, un);   // dpost = y * dout
+            if constexpr (RP) BD::template rows_out_rp<NCX>(aq, h, p, un, ps);    // dpost = y * dout
+            else BD::template rows_out<NCX>(aq, h, p, un);
           }
           // no barrier: phase C, rows_out and the rows_in / phase A that follow all stay inside the wave's own
           // column slice of E (same as between two pairs of the forward kernel)
         }
         if (act) {
-          BD::template rows_in<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ad, h, p, un);
+          if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
+          else BD::template rows_in<NCX>(ad, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1>(a.L, un, a.s_fwd);
+          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<true>(a, h, un, R, zs, slab, it == 0, W);
+          bwd_tiles<true, RP>(a, hk, un, R, zs, slab, it == 0, W, ps);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
         BD::unit_barrier();
         if (act) {
-          BD::template outer_stage<false, HALF && GEO::S1 == 1>(a.L, un);
+          BD::template outer_stage<false, HALF && GEO::S1 == 1, RP>(a.L, un, 1.0f, ps);
           B::lds_fence();
-          BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ao, h, p, un);
-          if (d.dpre) BD::template rows_out<(HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH>(ap, h, p, un);
+          if constexpr (RP) {
+            BD::template rows_out_rp<NCX>(ao, h, p, un, ps);
+            if (d.dpre) BD::template rows_out_rp<NCX>(ap, h, p, un, ps);
+          } else {
+            BD::template rows_out<NCX>(ao, h, p, un);
+            if (d.dpre) BD::template rows_out<NCX>(ap, h, p, un);
+          }
         }
       }
       w_acc_finish(slab, u, un, W);
@@ -759,10 +852,11 @@ struct Modes : Body<B, GEO, DT> {
   }
 
   // ------------------------------------------------------------------ dk_f -> dk
-  static FFC_FN void w_load(const DkArgs& a, int unit_id, int tau, A16& re, A16& im) {
+  // hmul: slab rows are (head, pass) for the multi-pass sizes (unit_id is then head * R + k0)
+  static FFC_FN void w_load(const DkArgs& a, int unit_id, int tau, A16& re, A16& im, int hmul = 1) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
-    const int64_t slab_stride = (int64_t)a.H * (GEO::NT * 2048);   // floats
+    const int64_t slab_stride = (int64_t)a.H * hmul * (GEO::NT * 2048);   // floats
     re = B::a16_zero(); im = B::a16_zero();
 #pragma unroll 1
     for (int s = 0; s < a.nslab; s++) {
@@ -830,6 +924,55 @@ struct Modes : Body<B, GEO, DT> {
       }
     }
   }
+  // multi-pass sizes: dk[n0 M + m] (+)= Re(i^q y_k0[m]) = {r, -s, -r, s}[q], q = n0 k0 4/R; fp32 accumulation over the passes
+  static FFC_FN void dk_rows_out_rp(const DkArgs& a, int unit_id, Unit un, Pass ps) {
+    const i32 lane = B::opaque(B::lane());
+    const int n0max = (a.Lk + GEO::N - 1) / GEO::N;
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + un.wq * 128 * GEO::S1;
+      pred sw;
+      i32 off = BD::pair_off(row, m, &sw) + un.eb;
+      u32 w[2][4];
+#pragma unroll
+      for (int pl = 0; pl < 2; pl++) {
+        U4 o = B::lds_r128(off + pl * GEO::PLANE);
+        w[pl][0] = B::sel(sw, o.z, o.x); w[pl][1] = B::sel(sw, o.w, o.y); w[pl][2] = B::sel(sw, o.x, o.z); w[pl][3] = B::sel(sw, o.y, o.w);
+      }
+      i32 hd = row * 0 + unit_id;
+      pred ok = hd < a.H;
+#pragma unroll 1
+      for (int n0 = 0; n0 < n0max; n0++) {
+        const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
+        const int pl = q & 1;
+        const float sg = (q == 0 || q == 3) ? 1.0f : -1.0f;
+        i32 n = row * GEO::Mi + m + n0 * GEO::N;
+        i32 e0 = hd * a.Lk + n;
+        f32 v[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          v[2 * k] = B::template unpack_lo<DT>(w[pl][k]) * sg; v[2 * k + 1] = B::template unpack_hi<DT>(w[pl][k]) * sg;
+        }
+        if (ps.k0 > 0) {
+          f32 old[8];
+          fload8(a.dk, e0, n, a.Lk, a.fast != 0, ok, old);
+#pragma unroll
+          for (int k = 0; k < 8; k++) v[k] = v[k] + old[k];
+        }
+        if (a.fast) {
+          U4 s0, s1;
+          s0.x = B::as_u32(v[0]); s0.y = B::as_u32(v[1]); s0.z = B::as_u32(v[2]); s0.w = B::as_u32(v[3]);
+          s1.x = B::as_u32(v[4]); s1.y = B::as_u32(v[5]); s1.z = B::as_u32(v[6]); s1.w = B::as_u32(v[7]);
+          B::g_w128(a.dk, e0 >> 2, s0, ok && (n < a.Lk));
+          B::g_w128(a.dk, (e0 >> 2) + 1, s1, ok && ((n + 4) < a.Lk));
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) B::g_w32(a.dk, e0 + k, B::as_u32(v[k]), ok && ((n + k) < a.Lk));
+        }
+      }
+    }
+  }
   static FFC_FN void dkifft(const DkArgs& a, int wg) {
     BD::setup_tables(a.tab, a.t);
     const int wv = B::wave();
@@ -842,6 +985,30 @@ struct Modes : Body<B, GEO, DT> {
     const bool act = unit_id < nunits;
     InnerRegs R;
     BD::load_inner(R, un);
+    if constexpr (GEO::N == 32768) {
+      if (a.R > 1) {        // multi-pass size: one inverse per pass, dk accumulated in fp32 by the same wave
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.R; k0++) {
+          const Pass ps = make_pass(a.tab, a.t, a.R, k0);
+          if (act) {
+#pragma unroll 1
+            for (int tt = 0; tt < GEO::TPW; tt++) {
+              A16 re, im;
+              w_load(a, unit_id * a.R + k0, un.wq * GEO::TPW + tt, re, im, a.R);
+              BD::template tile_inv<true, true>(a.s_inv, un.wq * GEO::TPW + tt, R, un, re, im, 0, ps);
+            }
+          }
+          B::barrier();
+          if (act) {
+            BD::template outer_stage<false, false, true>(a.Lk, un, 1.0f, ps);
+            B::lds_fence();
+            dk_rows_out_rp(a, unit_id, un, ps);
+          }
+          B::barrier();
+        }
+        return;
+      }
+    }
     if constexpr (GEO::OUTER) {
       if (act) {
 #pragma unroll 1

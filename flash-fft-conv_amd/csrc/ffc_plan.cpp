@@ -71,7 +71,13 @@ float f16_to_f32(uint16_t h) {
   return f;
 }
 
-bool plan_factors(int N, int* n1, int* n2, int* n3) {
+bool plan_factors(int N, int* n1, int* n2, int* n3, int* passes) {
+  if (passes) *passes = 1;
+  if (N == 65536 || N == 131072) {     // R passes of the 32 x 32 x 32 kernel
+    *n1 = 32; *n2 = 32; *n3 = 32;
+    if (passes) *passes = N / 32768;
+    return true;
+  }
   switch (N) {
     case 256: *n1 = 1; *n2 = 16; *n3 = 16; return true;
     case 512: *n1 = 1; *n2 = 16; *n3 = 32; return true;
@@ -126,6 +132,31 @@ void fill_mat(uint8_t* dst, int Nd, int dtype) {
         }
 }
 
+// Outer-digit operand table of pass k0 of an R-pass size (Nd = 32): the Nd-point DFT times the pass factor
+// W_{R Nd}^{n1 k0} on the INPUT index n1.  Same [out][contraction] operand layout as fill_mat.  Forward (phase A):
+// out = k1, contraction = n1: F[k1][n1] = W_Nd^{n1 k1} W_{R Nd}^{n1 k0}.  Inverse (phase C, used with the kernels' CONJ
+// flag): out = n1, contraction = k1, the factor sits on the OUTPUT index: T[n1][k1] = W_Nd^{n1 k1} W_{R Nd}^{n1 k0}.
+void fill_mat_pass(uint8_t* dst, int Nd, int dtype, int k0, int R, bool inverse) {
+  uint32_t* w = (uint32_t*)dst;
+  for (int ms = 0; ms < 2; ms++)
+    for (int which = 0; which < 3; which++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int d = 0; d < 4; d++) {
+          uint32_t word = 0;
+          for (int half = 0; half < 2; half++) {
+            int e = 2 * d + half;
+            int out = (lane & 31) % Nd, con = kslot_row(ms, lane >> 5, e) % Nd;
+            int n1 = inverse ? out : con;
+            long ph = ((long)out * con * R + (long)n1 * k0) % ((long)R * Nd);
+            double ang = -2.0 * kPi * (double)ph / (double)(R * Nd);
+            double re = cos(ang), im = sin(ang);
+            double v = which == 0 ? re : (which == 1 ? im : -im);
+            word |= (uint32_t)to_dt(v, dtype) << (16 * half);
+          }
+          w[((ms * 3 + which) * 64 + lane) * 4 + d] = word;
+        }
+}
+
 // ctab16: [rr 8][lane 64][re(2rr) im(2rr) re(2rr+1) im(2rr+1)]
 template <class F>
 void fill_ctab16(uint8_t* dst, F fn) {
@@ -149,7 +180,7 @@ void cis(double num, double den, double scale, double* re, double* im) {
 template <class GEO>
 void build(HostPlan* p) {
   Builder bl{p->blob};
-  const int N = GEO::N;
+  const int N = GEO::N * p->R;         // the fft size (R passes of the GEO::N kernel)
   p->NT = GEO::NT; p->NW = GEO::NW; p->G = GEO::G;
   int lg = 0;
   while ((1 << lg) < N) lg++;
@@ -176,72 +207,32 @@ void build(HostPlan* p) {
     int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
     cis((double)(n3 * k2), GEO::Mi, GEO::OUTER ? 1.0 : p->s_inv, re, im);
   });
-  t.base = bl.alloc(8192);
-  t.delta = bl.alloc(256);
-  t.omega = bl.alloc(256 * GEO::NW);
-  t.oi_a = bl.alloc(GEO::NT * 32 * GEO::SV * 8);
-  t.oi_b = bl.alloc(GEO::NT * GEO::SU * 2 * 16 * 8);
-  if (GEO::OUTER) {
-    fill_ctab16(p->blob.data() + t.base, [&](int lane, int r, double* re, double* im) {
-      int R = acc_row(r, lane >> 5), s1 = R / GEO::N1, k1 = R % GEO::N1, j = lane & 31;
-      cis(-(double)(s1 * 128 + 4 * j) * k1, N, p->s_fwd, re, im);
-    });
-    float* dl = (float*)(p->blob.data() + t.delta);
-    float* om = (float*)(p->blob.data() + t.omega);
-    for (int hi = 0; hi < 2; hi++)
-      for (int r = 0; r < 16; r++) {
-        int k1 = acc_row(r, hi) % GEO::N1;
-        double re, im;
-        cis(-(double)k1, N, 1.0, &re, &im);
-        dl[(hi * 16 + r) * 2] = (float)re; dl[(hi * 16 + r) * 2 + 1] = (float)im;
-        for (int w = 0; w < GEO::NW; w++) {
-          cis(-(double)(128 * GEO::S1 * w) * k1, N, 1.0, &re, &im);
-          om[((w * 2 + hi) * 16 + r) * 2] = (float)re; om[((w * 2 + hi) * 16 + r) * 2 + 1] = (float)im;
-        }
-      }
-    float* a = (float*)(p->blob.data() + t.oi_a);
-    float* bb = (float*)(p->blob.data() + t.oi_b);
-    for (int tau = 0; tau < GEO::NT; tau++) {
-      for (int c = 0; c < 32; c++)
-        for (int sV = 0; sV < GEO::SV; sV++) {
-          int sU = c / GEO::N2, n2 = c % GEO::N2;
-          int k1 = tau * GEO::G + sU * GEO::SV + sV;
-          double re, im;
-          cis((double)(n2 * GEO::N3) * k1, N, p->s_inv, &re, &im);
-          a[((tau * 32 + c) * GEO::SV + sV) * 2] = (float)re;
-          a[((tau * 32 + c) * GEO::SV + sV) * 2 + 1] = (float)im;
-        }
-      for (int sU = 0; sU < GEO::SU; sU++)
-        for (int hi = 0; hi < 2; hi++)
-          for (int r = 0; r < 16; r++) {
-            int V = acc_row(r, hi), sV = V / GEO::N3, n3 = V % GEO::N3;
-            int k1 = tau * GEO::G + sU * GEO::SV + sV;
-            double re, im;
-            cis((double)n3 * k1, N, 1.0, &re, &im);
-            int idx = ((tau * GEO::SU + sU) * 2 + hi) * 16 + r;
-            bb[idx * 2] = (float)re;
-            bb[idx * 2 + 1] = (float)im;
-          }
+  for (int k0 = 0; k0 < 4; k0++) t.matk[k0][0] = t.matk[k0][1] = t.mat[0];
+  for (int k0 = 1; k0 < p->R; k0++)
+    for (int inv = 0; inv < 2; inv++) {
+      t.matk[k0][inv] = bl.alloc(6 * 64 * 16);
+      fill_mat_pass(p->blob.data() + t.matk[k0][inv], GEO::N1, p->dtype, k0, p->R, inv != 0);
     }
-  }
   t.total = (int)p->blob.size();
-  p->kf_freq.resize((size_t)GEO::NT * 1024);
-  for (int tau = 0; tau < GEO::NT; tau++)
-    for (int rho = 0; rho < 8; rho++)
-      for (int U = 0; U < 32; U++)
-        for (int v = 0; v < 4; v++)
-          p->kf_freq[((tau * 8 + rho) * 32 + U) * 4 + v] = kf_freq<GEO>(tau, 4 * rho + v, U);
+  // internal position -> natural frequency: pass k0 holds f = k0 + R * f' (f' = the inner kernel's frequency)
+  p->kf_freq.resize((size_t)p->R * GEO::NT * 1024);
+  for (int k0 = 0; k0 < p->R; k0++)
+    for (int tau = 0; tau < GEO::NT; tau++)
+      for (int rho = 0; rho < 8; rho++)
+        for (int U = 0; U < 32; U++)
+          for (int v = 0; v < 4; v++)
+            p->kf_freq[(((size_t)k0 * GEO::NT + tau) * 8 + rho) * 128 + U * 4 + v] = k0 + p->R * kf_freq<GEO>(tau, 4 * rho + v, U);
 }
 
 }  // namespace
 
 bool build_plan(int N, int dtype, HostPlan* p) {
-  int n1, n2, n3;
-  if (!plan_factors(N, &n1, &n2, &n3)) return false;
+  int n1, n2, n3, passes;
+  if (!plan_factors(N, &n1, &n2, &n3, &passes)) return false;
   if (dtype != DT_BF16 && dtype != DT_F16) return false;
   *p = HostPlan();
-  p->N = N; p->N1 = n1; p->N2 = n2; p->N3 = n3; p->dtype = dtype;
-  switch (N) {
+  p->N = N; p->N1 = n1; p->N2 = n2; p->N3 = n3; p->dtype = dtype; p->R = passes;
+  switch (N / passes) {
     case 256: build<Geo<1, 16, 16>>(p); break;
     case 512: build<Geo<1, 16, 32>>(p); break;
     case 1024: build<Geo<1, 32, 32>>(p); break;

@@ -10,25 +10,26 @@ namespace ffc {
 struct PlanTabs {      // byte offsets into the plan blob
   int mat[3];          // operand tables of digits N1,N2,N3: [6][64][4] u32
   int twin, twin2;     // inner twiddle, fwd / inverse (ctab16)
-  int base;            // ctab16 : s_fwd * W_N^{(s1*128 + 4j)*k1}  (outer fwd twiddle of wave 0, tile 0)
-  int delta;           // [2 hi][16 r] complex f32 : W_N^{k1}            (tile -> tile+1 step)
-  int omega;           // [NW][2][16] complex f32 : W_N^{128*S1*w*k1}    (wave offset)
-  int oi_a;            // [NT][32][SV] complex f32 : W_N^{-n2*N3*k1}
-  int oi_b;            // [NT][SU][2][16] complex f32 : W_N^{-n3*k1}
+  // multi-pass sizes (HostPlan::R > 1): outer-digit operand tables of pass k0, [k0][0] forward, [k0][1] inverse
+  // (pass 0 uses mat[0] for both): F[k1][n1] = W_N1^{n1 k1} W_{R N1}^{n1 k0}, see ffc_plan.cpp fill_mat_pass
+  int matk[4][2];
   int total;
 };
 
 struct HostPlan {
   int N = 0, N1 = 0, N2 = 0, N3 = 0, dtype = 0;
-  int NT = 0, NW = 0, G = 0;
+  // R > 1: fft size N = R * (N1*N2*N3) run as R passes of the fused N1*N2*N3 kernel over the same rows (pass k0 = the
+  // frequencies f = k0 (mod R)): the radix-R step is folded into the outer digit's DFT matrix and twiddle chain
+  int R = 1;
+  int NT = 0, NW = 0, G = 0;        // NT: inner tiles per unit AND per pass (k_f has R*NT tiles per head)
   double s_fwd = 1, s_k = 1, s_inv = 1;   // s_fwd * s_k * s_inv == 1/N
   PlanTabs tabs{};
   std::vector<uint8_t> blob;
   std::vector<int32_t> kf_freq;  // internal position -> natural frequency, NT*1024 entries
 };
 
-// Supported sizes: 256,512,1024 (inner only) and 4096,8192,16384,32768 (outer x inner).
-bool plan_factors(int N, int* n1, int* n2, int* n3);
+// Supported sizes: 256,512,1024 (inner only), 4096,8192,16384,32768 (outer x inner), 65536,131072 (2 / 4 passes of 32768).
+bool plan_factors(int N, int* n1, int* n2, int* n3, int* passes = nullptr);
 bool build_plan(int N, int dtype, HostPlan* out);
 
 uint16_t f32_to_bf16(float f);

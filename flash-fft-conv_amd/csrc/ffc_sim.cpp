@@ -300,8 +300,18 @@ static void run_wg(int nwaves, int lds_bytes, F fn) {
 template <class GEO, int DT>
 static void sim_conv_t(const ConvArgs& a) {
   for (int h = 0; h < a.H; h++)
-    for (int c = 0; c < a.nchunk; c++)
+    for (int c = 0; c < a.nchunk; c++) {
+      if constexpr (GEO::N == 32768) {
+        if (a.R > 1) {       // mirrors conv_kernel<..., RP = true>: the passes run one after the other in the same workgroup
+          run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+            Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
+            Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
+          });
+          continue;
+        }
+      }
       run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Body<SimB, GEO, DT>::conv(a, h, c); });
+    }
 }
 
 template <template <class, int> class FN, class... A>
@@ -319,6 +329,8 @@ static int dispatch(int N, int dtype, A&&... args) {
     FFC_CASE(8192, 32, 16, 16)
     FFC_CASE(16384, 16, 32, 32)
     FFC_CASE(32768, 32, 32, 32)
+    FFC_CASE(65536, 32, 32, 32)       // multi-pass sizes: R passes of the 32768 kernel (HostPlan::R, struct Pass)
+    FFC_CASE(131072, 32, 32, 32)
   }
 #undef FFC_CASE
   return -1;
@@ -335,14 +347,32 @@ template <class GEO, int DT> struct DkfRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimBO, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+          if constexpr (GEO::N == 32768) {
+            if (d.c.R > 1) {
+              Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
+              for (int k0 = 0; k0 < d.c.R; k0++) Modes<SimBO, GEO, DT>::template dkf<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              return;
+            }
+          }
+          Modes<SimBO, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c);
+        });
   }
 };
 template <class GEO, int DT> struct BwdRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c); });
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+          if constexpr (GEO::N == 32768) {
+            if (d.c.R > 1) {
+              Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
+              for (int k0 = 0; k0 < d.c.R; k0++) Modes<SimBO, GEO, DT>::template bwd<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              return;
+            }
+          }
+          Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c);
+        });
   }
 };
 template <class GEO, int DT> struct DkRun {
@@ -394,7 +424,7 @@ int ffcsim_selftest_primitives(const uint32_t* in, uint32_t* out) {
 int ffcsim_plan_info(int N, int dtype, int* nt, double* s_fwd, double* s_k, int32_t* kf_freq /* nt*1024 or null */) {
   HostPlan p;
   if (!build_plan(N, dtype, &p)) return -1;
-  *nt = p.NT; *s_fwd = p.s_fwd; *s_k = p.s_k;
+  *nt = p.NT * p.R; *s_fwd = p.s_fwd; *s_k = p.s_k;      // k_f tiles per head (R passes x NT)
   if (kf_freq) memcpy(kf_freq, p.kf_freq.data(), p.kf_freq.size() * 4);
   return 0;
 }
@@ -411,6 +441,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
   a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
   a.fast = (L % 8 == 0) && !g_force_slow;
+  a.R = p.R;
   return dispatch<ConvRun>(N, dtype, a);
 }
 
@@ -456,6 +487,7 @@ int ffcsim_kernel_fft(int N, int dtype, const float* k, int H, int Lk, void* kf)
   a.s_fwd = (float)p.s_fwd;
   a.prescale = dtype == DT_F16 ? 256.f : 1.f;
   a.scale = (float)(p.s_k / p.s_fwd) / a.prescale; a.fast = (Lk % 4 == 0) && !g_force_slow;
+  a.R = p.R;
   return dispatch<KfRun>(N, dtype, a);
 }
 
@@ -475,6 +507,7 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   int ipc = (iters_total + nchunk - 1) / nchunk;
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
+  a.R = p.R;
   d.dout = dout; d.ws = ws;
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
@@ -498,6 +531,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   int ipc = (iters_total + nchunk - 1) / nchunk;
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
+  a.R = p.R;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
@@ -522,6 +556,7 @@ int ffcsim_kernel_ifft_grad(int N, int dtype, const float* ws, int nslab, int H,
   a.ws = ws; a.dk = dk; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = Lk; a.nslab = nslab;
   a.scale = (float)(1.0 / p.s_fwd); a.s_inv = (float)p.s_inv;   // tile_inv applies s_inv = 1/(N s_fwd)
   a.fast = (Lk % 4 == 0) && !g_force_slow;
+  a.R = p.R;
   return dispatch<DkRun>(N, dtype, a);
 }
 

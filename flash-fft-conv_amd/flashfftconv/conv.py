@@ -17,6 +17,12 @@ from . import bigfft as _big
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
+# fft sizes that run as R passes of the fused 32768 kernel (csrc/ffc_body.h struct Pass) instead of an HBM-level outer pass
+# around a smaller fused kernel (flashfftconv/bigfft.py).  The library has the kernels for 65536 (R = 2) and 131072 (R = 4);
+# measured (profiles/r02_multipass.txt) the 2-pass form is 1.4x faster than the HBM level at fft 65536, the 4-pass form
+# re-reads too much and loses to it at fft 131072, so only 65536 is routed here (FFC_MULTIPASS="65536,131072" / "" for A/B)
+import os as _os
+MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "65536,131072").split(",") if x.strip())
 # fft size 2048 has no 16/32-digit factorisation of its own: it runs on the 4096 plan with k periodised,
 # k' = [k_2048 | k_2048].  FFT_4096(k') is 2*FFT_2048(k) on the even bins and 0 on the odd ones, so the 4096-point
 # circular convolution with k' IS the 2048-point circular convolution with k (u occupies <= 2048 samples, the
@@ -231,7 +237,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
         pregate = None if pregate is None else pregate.contiguous()
         postgate = None if postgate is None else postgate.contiguous()
         ctx.mod, ctx.k_len, ctx.k_dtype, ctx.gated = mod, k.shape[-1], k.dtype, pregate is not None
-        ctx.big = mod.seqlen in _big.BIG_FACTORS
+        ctx.big = mod._big
         if ctx.big:
             out, kf = _big_forward(mod, u, k, pregate, postgate)
         else:
@@ -319,6 +325,7 @@ class FlashFFTConv(torch.nn.Module):
         if seqlen not in SUPPORTED_SEQLENS:
             raise NotImplementedError(f"seqlen {seqlen} not supported")
         self.seqlen = seqlen
+        self._big = seqlen in _big.BIG_FACTORS and seqlen not in MULTIPASS_SEQLENS
         self._folded = seqlen in FOLDED_SEQLENS
         self._plan_seqlen = FOLDED_SEQLENS.get(seqlen, seqlen)
         self.dtype = dtype

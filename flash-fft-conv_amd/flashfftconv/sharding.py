@@ -207,7 +207,7 @@ class BatchShardedFFTConv(torch.nn.Module):
         mode = self.mode
         if self._ops is None and mode == "allgather_kf":
             from . import bigfft
-            if self.conv.seqlen in bigfft.BIG_FACTORS or self.conv._folded or self.conv._kf_keep is not None:
+            if self.conv._big or self.conv._folded or self.conv._kf_keep is not None:
                 mode = "recompute"          # k_f of these sizes is not a single fused plan's tensor
         if mode == "recompute":
             kk = _AllReduceGrad.apply(k, self.group)

@@ -170,3 +170,49 @@ def test_fused_backward(N, L, B, H, nch, gated, dt):
         r = O.ref_grads(q(u, dt), k, q(d, dt), N)
     assert rel(S.from_bits(du, dt), r[0]) < TOL[dt]
     assert rel(dk, r[1]) < 1.5 * TOL[0]
+
+
+# ---------------------------------------------------------------- multi-pass sizes (fft 65536 / 131072 = 2 / 4 passes of
+# the fused 32768 kernel, csrc/ffc_body.h struct Pass): every mode, padded / full / ragged lengths (1, 2 or 4 input blocks)
+@pytest.mark.parametrize("N,L,B", [(65536, 32768, 3), (65536, 65536, 2), (65536, 16384, 2), (65536, 40004, 1), (65536, 1002, 2),
+                                   (131072, 65536, 2), (131072, 131072, 1), (131072, 32768, 2), (131072, 100000, 1)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_multipass_forward(N, L, B, dt):
+    rng = np.random.default_rng(N + L + dt)
+    H = 2 if L <= 32768 else 1
+    u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)                       # kfft kernel, multi-pass
+    assert rel(S.from_bits(kf, dt), S.from_bits(S.make_kf_internal(k, N, dt), dt).astype(np.float64)) < (8e-3 if dt == 0 else 1e-3)
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf), dt)
+    assert rel(y, O.ref_fft_conv(q(u, dt), k, N)) < TOL[dt]
+    yg = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, S.to_bits(g1, dt), S.to_bits(g2, dt)), dt)
+    assert rel(yg, O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype=NAME[dt])) < TOL[dt]
+    du = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, conj=1), dt)      # conj(k_f): the input-gradient pass
+    dref, _ = O.ref_grads(np.zeros_like(u), k, q(u, dt), N)
+    assert rel(du, dref) < TOL[dt]
+
+
+@pytest.mark.parametrize("N,L,B,H,nch,gated", [(65536, 32768, 3, 2, 2, True), (65536, 65536, 2, 1, 1, False), (65536, 8192, 5, 1, 1, False),
+                                               (131072, 65536, 3, 1, 1, True), (131072, 131072, 2, 1, 1, False)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_multipass_backward(N, L, B, H, nch, gated, dt):
+    rng = np.random.default_rng(N + L)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    du, dpre, dk = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, L, pre, post, nch)
+    if gated:
+        r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt))
+        assert rel(S.from_bits(dpre, dt), r[2]) < TOL[dt]
+        assert rel(S.from_bits(S.sim_bwd.dpost, dt), r[3]) < TOL[dt]
+    else:
+        r = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(S.from_bits(du, dt), r[0]) < TOL[dt]
+    assert rel(dk, r[1]) < 1.5 * TOL[0]
+    # the dk_f-only kernel (Modes::dkf) + inverse, shorter dk than L
+    Lk = L - 4
+    dk2 = S.sim_dk(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), Lk, pre, post, nchunk=nch)
+    assert rel(dk2, r[1][:, :Lk]) < 1.5 * TOL[0]
