@@ -48,6 +48,10 @@ struct ConvArgs {
   int stream;            // 1: activation rows through non-temporal accesses (set by the host when every row is touched once)
   int persist;           // grid cap of the persistent one-wave-per-unit kernels (CU count rounded down to 8)
   int R;                 // > 1: multi-pass size, fft size = R * GEO::N (HostPlan::R); 0 / 1: single pass
+  // batch strides in elements of u / pregate / postgate / y (row (b, h) starts at b * stride + h * L): H * L for contiguous
+  // tensors; larger when the tensor is a channel slice of a wider (B, C, L) tensor (FlashHyenaOp: x1, x2, v are slices of the
+  // short convolution's (B, 3D, L) output and are read in place)
+  int64_t sbu, sbg, sbp, sby;
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -295,6 +299,7 @@ struct Body {
   // 16K 0.667 -> 0.638, 32K 1.043 -> 1.025.  Not used in the gated backward, where the same workgroup reads u, dout and
   // the gates a second time as output gates (cfg3: 0.839 -> 0.865 with streaming).
   static constexpr bool STREAM_ROWS = FFC_STREAM_ROWS != 0;
+  static FFC_FN int64_t row_off(int b, bool ok, int64_t sb, int h, int L) { return (int64_t)(ok ? b : 0) * sb + (int64_t)h * L; }
   struct RowIO {
     const uint16_t* src[2]; const uint16_t* gate[2]; uint16_t* dst[2]; bool valid[2];
   };
@@ -358,11 +363,11 @@ struct Body {
           if (fast && ((i * 64) / CPR) * GEO::Mi >= a.L) { X.v[i][pl] = U4{B::uconst(0), B::uconst(0), B::uconst(0), B::uconst(0)}; continue; }
           const int b = 2 * pq + pl;
           const bool ok = b < a.B;
-          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+          const int64_t ro = row_off(b, ok, a.sbu, h, a.L);
           X.v[i][pl] = gload8((const uint16_t*)a.u + ro, row * GEO::Mi + m, a.L, fast, ok);
         } else {
           i32 b = (row + pq * GEO::G) * 2 + pl;
-          X.v[i][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, m, fast, b < a.B);
+          X.v[i][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, a.sbu, m, fast, b < a.B);
         }
       }
     }
@@ -391,11 +396,11 @@ struct Body {
           if constexpr (GEO::OUTER) {
             const int b = 2 * pq + pl;
             const bool ok = b < a.B;
-            const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
+            const int64_t ro = row_off(b, ok, a.sbg, h, a.L);
             g = gload8((const uint16_t*)a.pregate + ro, row * GEO::Mi + m, a.L, fast, ok);
           } else {
             i32 b = (row + pq * GEO::G) * 2 + pl;
-            g = gload8_rows((const uint16_t*)a.pregate, b, h, a, m, fast, b < a.B);
+            g = gload8_rows((const uint16_t*)a.pregate, b, h, a, a.sbg, m, fast, b < a.B);
           }
           v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
         }
@@ -414,15 +419,16 @@ struct Body {
   }
   // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
   // 32 bits in 16-byte units (launcher checks the tensor size).
-  static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, int fast, pred ok) {
+  static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, int64_t sb, i32 n, int fast, pred ok) {
+    const int sbi = (int)sb;      // the launcher checks B * stride < 2^31 (and stride % 8 == 0 for the fast path)
     if (fast) {
-      i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
+      i32 o16 = b * (sbi >> 3) + (h * (a.L >> 3) + (n >> 3));
       return B::g_r128p(base, o16, ok && (n < a.L));
     }
     u32 w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      i32 e0 = (b * a.H + h) * a.L + n + 2 * q;
+      i32 e0 = b * sbi + (h * a.L + n + 2 * q);
       u32 lo = B::g_r16(base, e0, ok && ((n + 2 * q) < a.L));
       u32 hi = B::g_r16(base, e0 + 1, ok && ((n + (2 * q + 1)) < a.L));
       w[q] = lo | (hi << 16);
@@ -430,16 +436,17 @@ struct Body {
     U4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     return v;
   }
-  static FFC_FN void gstore8_rows(uint16_t* base, i32 b, int h, const ConvArgs& a, i32 n, int fast, pred ok, U4 v) {
+  static FFC_FN void gstore8_rows(uint16_t* base, i32 b, int h, const ConvArgs& a, int64_t sb, i32 n, int fast, pred ok, U4 v) {
+    const int sbi = (int)sb;
     if (fast) {
-      i32 o16 = (b * a.H + h) * (a.L >> 3) + (n >> 3);
+      i32 o16 = b * (sbi >> 3) + (h * (a.L >> 3) + (n >> 3));
       B::g_w128(base, o16, v, ok && (n < a.L));
       return;
     }
     u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      i32 e0 = (b * a.H + h) * a.L + n + 2 * q;
+      i32 e0 = b * sbi + (h * a.L + n + 2 * q);
       B::g_w16(base, e0, w[q] & 0xffffu, ok && ((n + 2 * q) < a.L));
       B::g_w16(base, e0 + 1, w[q] >> 16, ok && ((n + (2 * q + 1)) < a.L));
     }
@@ -464,21 +471,20 @@ struct Body {
         if constexpr (GEO::OUTER) {
           const int b = 2 * pq + pl;
           const bool ok = b < a.B;
-          const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
           i32 n = row * GEO::Mi + m;
           if (a.postgate) {
-            U4 g = gload8((const uint16_t*)a.postgate + ro, n, a.L, fast, ok);
+            U4 g = gload8((const uint16_t*)a.postgate + row_off(b, ok, a.sbp, h, a.L), n, a.L, fast, ok);
             v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
           }
-          gstore8((uint16_t*)a.y + ro, n, a.L, fast, ok, v);
+          gstore8((uint16_t*)a.y + row_off(b, ok, a.sby, h, a.L), n, a.L, fast, ok, v);
         } else {
           i32 b = (row + pq * GEO::G) * 2 + pl;
           pred ok = b < a.B;
           if (a.postgate) {
-            U4 g = gload8_rows((const uint16_t*)a.postgate, b, h, a, m, fast, ok);
+            U4 g = gload8_rows((const uint16_t*)a.postgate, b, h, a, a.sbp, m, fast, ok);
             v.x = mul2(v.x, g.x); v.y = mul2(v.y, g.y); v.z = mul2(v.z, g.z); v.w = mul2(v.w, g.w);
           }
-          gstore8_rows((uint16_t*)a.y, b, h, a, m, fast, ok, v);
+          gstore8_rows((uint16_t*)a.y, b, h, a, a.sby, m, fast, ok, v);
         }
       }
     }
@@ -507,10 +513,9 @@ struct Body {
   // (u * pregate)[n .. n+7] of batch row b, zero beyond L / for a missing row
   static FFC_FN U4 load_gated(const ConvArgs& a, int h, int b, i32 n, int fast) {
     const bool ok = b < a.B;
-    const int64_t ro = ((int64_t)(ok ? b : 0) * a.H + h) * a.L;
-    U4 v = gload8((const uint16_t*)a.u + ro, n, a.L, fast, ok);
+    U4 v = gload8((const uint16_t*)a.u + row_off(b, ok, a.sbu, h, a.L), n, a.L, fast, ok);
     if (fast) v = mask4(v, (n < a.L) && ok);
-    if (a.pregate) v = mul4(v, gload8((const uint16_t*)a.pregate + ro, n, a.L, fast, ok));
+    if (a.pregate) v = mul4(v, gload8((const uint16_t*)a.pregate + row_off(b, ok, a.sbg, h, a.L), n, a.L, fast, ok));
     return v;
   }
   // rows_in of pass k0: E row n1 = sum_n0 W_R^{n0 k0} (u * pregate)[n0 M + n1 Mi + m]; plane 0 = Re (batch row 2p),
@@ -555,11 +560,12 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
     const int n0max = (a.L + GEO::N - 1) / GEO::N;
-    int64_t ro[2]; bool okb[2];
+    int64_t ro[2], rg[2]; bool okb[2];
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
       okb[pl] = (2 * pq + pl) < a.B;
-      ro[pl] = ((int64_t)(okb[pl] ? 2 * pq + pl : 0) * a.H + h) * a.L;
+      ro[pl] = row_off(2 * pq + pl, okb[pl], a.sby, h, a.L);
+      rg[pl] = row_off(2 * pq + pl, okb[pl], a.sbp, h, a.L);
     }
 #pragma unroll 1
     for (int n0 = 0; n0 < n0max; n0++) {
@@ -597,7 +603,7 @@ struct Body {
           // plane 0: {r, -s, -r, s}[q], plane 1: {s, r, -s, -r}[q]
           U4 c = ((q & 1) != 0) == (pl == 0) ? y[1] : y[0];
           const float sg = pl == 0 ? ((q == 0 || q == 3) ? 1.0f : -1.0f) : (q < 2 ? 1.0f : -1.0f);
-          if (a.postgate) c = mul4(c, gload8((const uint16_t*)a.postgate + ro[pl], n, a.L, fast, okb[pl]));
+          if (a.postgate) c = mul4(c, gload8((const uint16_t*)a.postgate + rg[pl], n, a.L, fast, okb[pl]));
           if (ps.k0 > 0) c = add4(HOIST ? old.v[HOIST ? i : 0][pl] : gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]), c, sg);
           gstore8((uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl], c);
         }

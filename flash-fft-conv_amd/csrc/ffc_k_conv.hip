@@ -76,27 +76,43 @@ struct ConvLaunch {
   }
 };
 
-extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
-                            int64_t B, int64_t H, int64_t L, int conj_kf, void* stream) {
+// stride 0 = contiguous (H * L)
+static inline bool ffc_stride_ok(int64_t* sb, int64_t B, int64_t H, int64_t L) {
+  if (*sb == 0) *sb = H * L;
+  return *sb >= H * L && (B - 1) * *sb + H * L < ((int64_t)1 << 31);
+}
+
+extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
+                                    void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                                    int64_t sb_post, int64_t sb_y, void* stream) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
   if ((uintptr_t)kf & 15) return ffc_fail("k_f must be 16-byte aligned");
-  if (B * H * L >= ((int64_t)1 << 31)) return ffc_fail("tensor too large (>= 2^31 elements)");
+  if (!ffc_stride_ok(&sb_u, B, H, L) || !ffc_stride_ok(&sb_pre, B, H, L) || !ffc_stride_ok(&sb_post, B, H, L) ||
+      !ffc_stride_ok(&sb_y, B, H, L))
+    return ffc_fail("tensor too large (>= 2^31 elements) or batch stride smaller than H*L");
   ConvArgs a{};
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
   a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
+  a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_y;
   a.conj_kf = conj_kf;
   a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.flags = p->env_flags;
-  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
+  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15) &&
+           !((sb_u | sb_pre | sb_post | sb_y) & 7);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = ffc_persist(p);
   a.R = p->hp.R;
   // every row is read / written exactly once per launch (multi-pass sizes re-read the rows in every pass: plain accesses)
   a.stream = p->env_stream >= 0 ? p->env_stream : (p->hp.R > 1 ? 0 : 1);
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
+                            int64_t B, int64_t H, int64_t L, int conj_kf, void* stream) {
+  return ffc_conv_fwd_strided(p, u, kf, pregate, postgate, y, B, H, L, conj_kf, 0, 0, 0, 0, stream);
 }
 
 // ---- profiling build (N = 32768, bf16 only): same body with s_memtime phase counters
@@ -127,6 +143,7 @@ extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* k
   a.u = u; a.y = y; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.fast = (L % 8 == 0);
+  a.sbu = a.sbg = a.sbp = a.sby = H * L;
   a.flags = p->env_flags;
   a.prof = prof;
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);

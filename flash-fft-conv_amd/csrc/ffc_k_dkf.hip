@@ -197,6 +197,7 @@ extern "C" int ffc_conv_bwd_dkf(const ffc_plan* p, const void* dout, const void*
   ConvArgs& a = d.c;
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_fwd = (float)p->hp.s_fwd;
+  a.sbu = a.sbg = a.sbp = a.sby = H * L; d.sbd = d.sbdu = d.sbdpre = d.sbdpost = H * L;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate) & 15);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   a.persist = ffc_persist(p);
@@ -220,19 +221,34 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
 }
 // + dpost = dout * conv(u*pregate, k) (nullable).  Fused sizes >= 4096 produce it inside the same launch (one extra
 // inverse transform per pair); the single-tile sizes (N <= 1024) run the forward kernel with dout as the output gate.
-extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
-                                  const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
-                                  int64_t L, void* stream) {
+// Batch strides in elements (0 = contiguous H * L): every tensor may be a channel slice of a wider (B, C, L) tensor.
+extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
+                                    void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                                    int64_t sb_post, int64_t sb_y, void* stream);
+extern "C" int ffc_conv_bwd_gated_strided(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                                          int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
   if ((uintptr_t)kf & 15) return ffc_fail("k_f must be 16-byte aligned");
-  if (B * H * L >= ((int64_t)1 << 31)) return ffc_fail("tensor too large (>= 2^31 elements)");
+  int64_t* sbs[7] = {&sb_dout, &sb_u, &sb_pre, &sb_post, &sb_du, &sb_dpre, &sb_dpost};
+  int64_t any = 0;
+  for (int i = 0; i < 7; i++) {
+    if (*sbs[i] == 0) *sbs[i] = H * L;
+    if (*sbs[i] < H * L || (B - 1) * *sbs[i] + H * L >= ((int64_t)1 << 31))
+      return ffc_fail("tensor too large (>= 2^31 elements) or batch stride smaller than H*L");
+    any |= *sbs[i];
+  }
   DkfArgs d{};
   ConvArgs& a = d.c;
   a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p->d_blob; a.t = p->hp.tabs;
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2); a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
-  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15);
+  a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_du;
+  d.sbd = sb_dout; d.sbdu = sb_du; d.sbdpre = sb_dpre; d.sbdpost = sb_dpost;
+  a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)dout | (uintptr_t)pregate | (uintptr_t)postgate | (uintptr_t)du | (uintptr_t)dpre) & 15) &&
+           !(any & 7);
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
   a.persist = ffc_persist(p);
   a.R = p->hp.R;
@@ -243,5 +259,10 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
   if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;
   int rc = ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
   if (rc || !dpost || d.dpost) return rc;
-  return ffc_conv_fwd(p, u, kf, pregate, dout, dpost, B, H, L, 0, stream);
+  return ffc_conv_fwd_strided(p, u, kf, pregate, dout, dpost, B, H, L, 0, sb_u, sb_pre, sb_dout, sb_dpost, stream);
+}
+extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                                  const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                                  int64_t L, void* stream) {
+  return ffc_conv_bwd_gated_strided(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream);
 }

@@ -31,6 +31,7 @@ struct DkfArgs {
   ConvArgs c;          // u / pregate / postgate as in the forward; c.y unused
   const void* dout;
   float* ws;           // [nchunk*UPW][H][NT*1024][2] fp32 partial sums (internal order)
+  int64_t sbd, sbdu, sbdpre, sbdpost;   // batch strides (elements) of dout / du / dpre / dpost (see ConvArgs::sbu)
   // fused backward (Modes::bwd) only: c.kf = k_f, du = pregate * corr(dout*postgate, k),
   // dpre = u * corr(dout*postgate, k) (nullable)
   void* du;
@@ -228,7 +229,7 @@ struct Modes : Body<B, GEO, DT> {
       if (act) {
         if (a.xpair) {
           ConvArgs cv{};
-          cv.u = a.xpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1;
+          cv.u = a.xpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1; cv.sbu = (int64_t)a.H * GEO::N;
           BD::rows_in(cv, unit_id, 0, un);
         } else {
           k_rows_in(a, unit_id, un);
@@ -577,7 +578,7 @@ struct Modes : Body<B, GEO, DT> {
     if (p1 > a.npair) p1 = a.npair;
     ConvArgs av = a;            // v = u * pregate
     ConvArgs ad = a;            // dc = dout * postgate
-    ad.u = d.dout; ad.pregate = a.postgate;
+    ad.u = d.dout; ad.pregate = a.postgate; ad.sbu = d.sbd; ad.sbg = a.sbp;
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
     // Multi-pass sizes: slab rows are (head, pass).
     float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
@@ -709,13 +710,13 @@ struct Modes : Body<B, GEO, DT> {
     if (p1 > a.npair) p1 = a.npair;
     ConvArgs av = a;            // v = u * pregate
     ConvArgs ad = a;            // dc = dout * postgate
-    ad.u = d.dout; ad.pregate = a.postgate;
+    ad.u = d.dout; ad.pregate = a.postgate; ad.sbu = d.sbd; ad.sbg = a.sbp;
     ConvArgs ao = a;            // du = dv * pregate
-    ao.y = d.du; ao.postgate = a.pregate;
+    ao.y = d.du; ao.postgate = a.pregate; ao.sby = d.sbdu; ao.sbp = a.sbg;
     ConvArgs ap = a;            // dpre = dv * u
-    ap.y = d.dpre; ap.postgate = a.u;
+    ap.y = d.dpre; ap.postgate = a.u; ap.sby = d.sbdpre; ap.sbp = a.sbu;
     ConvArgs aq = a;            // dpost = conv(u*pregate, k) * dout
-    aq.y = d.dpost; aq.postgate = d.dout;
+    aq.y = d.dpost; aq.postgate = d.dout; aq.sby = d.sbdpost; aq.sbp = d.sbd;
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
     // Multi-pass sizes: slab rows are (head, pass).
     float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
@@ -1024,7 +1025,7 @@ struct Modes : Body<B, GEO, DT> {
         B::lds_fence();
         if (a.outpair) {
           ConvArgs cv{};
-          cv.y = a.outpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1;
+          cv.y = a.outpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N; cv.fast = 1; cv.sby = (int64_t)a.H * GEO::N;
           BD::rows_out(cv, unit_id, 0, un);
         } else {
           dk_rows_out(a, unit_id, un);

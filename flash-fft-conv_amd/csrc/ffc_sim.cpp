@@ -439,6 +439,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.y = y; a.kf = kf;
   a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2;
+  a.sbu = a.sbg = a.sbp = a.sby = (int64_t)H * L;
   a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
   a.fast = (L % 8 == 0) && !g_force_slow;
   a.R = p.R;
@@ -500,6 +501,7 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   ConvArgs& a = d.c;
   a.u = u; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_fwd = (float)p.s_fwd;
+  a.sbu = a.sbg = a.sbp = a.sby = (int64_t)H * L; d.sbd = d.sbdu = d.sbdpre = d.sbdpost = (int64_t)H * L;
   int upw = ffcsim_upw(N);
   int per_iter = p.N1 > 1 ? upw : upw * p.G;
   int iters_total = (a.npair + per_iter - 1) / per_iter;
@@ -524,6 +526,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   ConvArgs& a = d.c;
   a.u = u; a.kf = kf; a.pregate = pregate; a.postgate = postgate; a.tab = p.blob.data(); a.t = p.tabs;
   a.B = B; a.H = H; a.L = L; a.npair = (B + 1) / 2; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
+  a.sbu = a.sbg = a.sbp = a.sby = (int64_t)H * L; d.sbd = d.sbdu = d.sbdpre = d.sbdpost = (int64_t)H * L;
   int upw = ffcsim_upw(N);
   int per_iter = p.N1 > 1 ? upw : upw * p.G;
   int iters_total = (a.npair + per_iter - 1) / per_iter;

@@ -3,6 +3,8 @@
 from .conv import FlashFFTConv
 from .depthwise_1d import FlashDepthWiseConv1d
 from .sparse_conv import PartialFFTConv, FrequencySparseFFTConv
+from .hyena import FlashHyenaOp, gated_conv_from_slices
 
 FlashDepthwiseConv1d = FlashDepthWiseConv1d  # README spelling of the reference
-__all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d", "PartialFFTConv", "FrequencySparseFFTConv"]
+__all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d", "PartialFFTConv", "FrequencySparseFFTConv",
+           "FlashHyenaOp", "gated_conv_from_slices"]

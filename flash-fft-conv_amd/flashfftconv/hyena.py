@@ -1,0 +1,107 @@
+"""Fused Hyena / Monarch-Mixer sequence operator on the MI355X kernels.
+
+The reference's callers build the gated long convolution out of separate kernels around FlashFFTConv
+(examples/hyena-dna/hyenadna_flashfftconv.py:269-289, examples/bert/monarch_mixer_sequence_mixer_flashfftconv.py:118-175):
+
+    uc = flash_short_filter(u)[..., :l]            # depthwise k=3 conv over the 3*D projected channels
+    x1, x2, v = uc.split(d_model, dim=1)           # three (B, D, L) channel slices (non-contiguous)
+    x1v = (x1 * v).contiguous()                    # elementwise kernel + copy
+    y = flashfftconv(x1v, k)                       # FFT convolution
+    y = y * x2                                     # elementwise kernel
+
+Here the three slices are handed to the gated FFT-conv kernel IN PLACE (batch-strided rows, ffc_conv_fwd_strided): v is the
+input, x1 the pregate, x2 the postgate, so the multiply kernels, the copy and their HBM round trips disappear, in the forward
+and in the backward (du / dpregate / dpostgate are written straight into the slices of d(uc), one launch; then the short
+convolution's own backward).  y = x2 * conv(x1 * v, k): the same function as the reference composition."""
+import torch
+
+from . import _lib
+from .conv import FlashFFTConv, _check_inputs, _kernel_fft, _periodise_k
+from .depthwise_1d import FlashDepthWiseConv1d
+
+
+def _slice_ptr(t, j, D, L):
+    return _lib.ctypes.c_void_p(t.data_ptr() + j * D * L * t.element_size())
+
+
+class _GatedSlicesFn(torch.autograd.Function):
+    """y = uc[:, 1] * conv(uc[:, 0] * uc[:, 2], k) for uc viewed as (B, 3, D, L): x1 = slice 0, x2 = slice 1, v = slice 2."""
+
+    @staticmethod
+    def forward(ctx, uc, k, mod):
+        B, D3, L = uc.shape
+        D = D3 // 3
+        plan = mod._get_plan(uc.device, mod._plan_seqlen)
+        with torch.cuda.device(uc.device):
+            kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
+            y = torch.empty(B, D, L, dtype=uc.dtype, device=uc.device)
+            sb = D3 * L
+            _lib.check(_lib.lib().ffc_conv_fwd_strided(plan.handle, _slice_ptr(uc, 2, D, L), _lib.ptr(kf), _slice_ptr(uc, 0, D, L),
+                                                       _slice_ptr(uc, 1, D, L), _lib.ptr(y), B, D, L, 0, sb, sb, sb, 0,
+                                                       _lib.stream_ptr()), "ffc_conv_fwd_strided")
+        ctx.mod, ctx.k_len, ctx.k_dtype = mod, k.shape[-1], k.dtype
+        if mod.training:
+            ctx.save_for_backward(uc, kf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.saved_tensors:
+            raise RuntimeError("FlashHyenaOp: backward needs module.training=True at forward time")
+        uc, kf = ctx.saved_tensors
+        mod = ctx.mod
+        B, D3, L = uc.shape
+        D = D3 // 3
+        plan = mod._get_plan(uc.device, mod._plan_seqlen)
+        lib = _lib.lib()
+        with torch.cuda.device(uc.device):
+            dy = dy.contiguous()
+            duc = torch.empty_like(uc)
+            ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, D), dtype=torch.uint8, device=uc.device)
+            sb = D3 * L
+            # u = v (slice 2), pregate = x1 (slice 0), postgate = x2 (slice 1); gradients land in the same slices of duc
+            _lib.check(lib.ffc_conv_bwd_gated_strided(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
+                                                      _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
+                                                      _slice_ptr(duc, 0, D, L), _slice_ptr(duc, 1, D, L), _lib.ptr(ws), B, D, L,
+                                                      0, sb, sb, sb, sb, sb, sb, _lib.stream_ptr()), "ffc_conv_bwd_gated_strided")
+            k_len = plan.seqlen if mod._folded else ctx.k_len
+            dk = torch.empty(D, k_len, dtype=torch.float32, device=uc.device)
+            _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, D, k_len, _lib.ptr(dk), _lib.stream_ptr()),
+                       "ffc_kernel_ifft_grad")
+            if mod._folded:
+                n = mod.seqlen
+                dk = (dk[:, :n] + dk[:, n:])[:, :ctx.k_len]
+        return duc, dk.to(ctx.k_dtype), None
+
+
+def gated_conv_from_slices(conv, uc, k):
+    """y = x2 * conv(x1 * v, k) with (x1, x2, v) = uc.split(D, dim=1), uc (B, 3D, L) contiguous, through `conv`
+    (a FlashFFTConv).  Sizes served by the fused kernels (fft <= 131072) read the slices in place; larger ones fall back to
+    the module's gated call on contiguous copies (same result)."""
+    if uc.dim() != 3 or uc.shape[1] % 3:
+        raise RuntimeError("gated_conv_from_slices: uc must be (B, 3*D, L)")
+    D, L = uc.shape[1] // 3, uc.shape[2]
+    if conv._big or conv._kf_keep is not None or (D * L) % 8 or not uc.is_contiguous():
+        x1, x2, v = (t.contiguous() for t in uc.split(D, dim=1))
+        return conv(v, k, x1, x2)
+    _check_inputs(conv, uc[:, :D], k, ())
+    return _GatedSlicesFn.apply(uc, k, conv)
+
+
+class FlashHyenaOp(torch.nn.Module):
+    """short depthwise conv (k = 3, "same" length) over the 3*D projected channels, then y = x2 * fftconv(x1 * v, k).
+
+    forward(x1x2v, k): x1x2v (B, 3*D, L) bf16/fp16 (the in-projection's output, channels first), k (D, Lk) fp32 -> (B, D, L).
+    `short_filter_weight` (3D, 1, 3) or (3D, 3) and `short_filter_bias` (3D,) are the nn.Conv1d parameters the reference
+    callers pass to FlashDepthWiseConv1d (hyenadna_flashfftconv.py:248-261: padding=1, i.e. the [..., :l] crop is a no-op)."""
+
+    def __init__(self, d_model, fft_size, short_filter_weight, short_filter_bias, dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.d_model = d_model
+        self.short_filter = FlashDepthWiseConv1d(3 * d_model, 3, 1, short_filter_weight, short_filter_bias, is_bhl=True,
+                                                 device=device, dtype=dtype)
+        self.flashfftconv = FlashFFTConv(fft_size, dtype=dtype)
+
+    def forward(self, x1x2v, k):
+        uc = self.short_filter(x1x2v)
+        return gated_conv_from_slices(self.flashfftconv, uc, k)

@@ -49,6 +49,15 @@ int ffc_kf_pack(const ffc_plan* plan, const void* kf_natural_c64, int64_t H, voi
 int ffc_conv_fwd(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate,
                  void* y, int64_t B, int64_t H, int64_t L, int conj_kf, void* stream);
 
+/* Same with batch strides in ELEMENTS (0 = contiguous, H * L): row (b, h) of a tensor starts at b * stride + h * L, so u,
+ * the gates and y may each be a channel slice of a wider (B, C, L) tensor, read / written in place.  This is what lets the
+ * fused Hyena / M2 operator (flashfftconv/hyena.py; reference callers examples/hyena-dna/hyenadna_flashfftconv.py:274-284,
+ * examples/bert/monarch_mixer_sequence_mixer_flashfftconv.py:127-170) feed x1, x2, v = split(short_conv(...)) to the
+ * gated kernel without the x1*v, y*x2 elementwise kernels and the .contiguous() copies. */
+int ffc_conv_fwd_strided(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate,
+                         void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                         int64_t sb_post, int64_t sb_y, void* stream);
+
 /* dk_f accumulation: dkf[h, :] (fp32 complex, internal order, scaled) = sum_b FFT(dout*postgate) * conj(FFT(u*pregate)).
  * ws: workspace of ffc_dkf_workspace_bytes() bytes (partial sums per chunk of batch pairs). */
 int64_t ffc_dkf_workspace_bytes(const ffc_plan* plan, int64_t B, int64_t H);
@@ -68,6 +77,10 @@ int ffc_conv_bwd(const ffc_plan* plan, const void* dout, const void* u, const vo
 int ffc_conv_bwd_gated(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
                        const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H, int64_t L,
                        void* stream);
+int ffc_conv_bwd_gated_strided(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
+                               const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                               int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_du,
+                               int64_t sb_dpre, int64_t sb_dpost, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);
@@ -76,7 +89,9 @@ int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_
 int ffc_kernel_ifft_grad_slabs(const ffc_plan* plan, const void* slabs, int64_t nslab, int64_t H, int64_t Lk, float* dk,
                                void* stream);
 
-/* FFT sizes 65536..4194304 = one or two outer DFT levels (factor n0 = 16 or 32) through HBM around a
+/* FFT sizes 65536 and 131072 are PLAN sizes too (ffc_plan_create(65536 | 131072)): they run as 2 / 4 passes of the fused 32768
+ * kernel over the same rows (csrc/ffc_body.h struct Pass) through the entry points above; k_f then holds R * 32 tiles per head.
+ * FFT sizes 262144..4194304 (and 65536 / 131072 on request) = one or two outer DFT levels (factor n0 = 16 or 32) through HBM around a
  * fused inner size (replaces butterfly_{,padded_}{,gated_}{,ifft_}*forward, monarch.cpp:41-56, and the
  * *_complex monarch exports :22-38).  The host chains the passes (flashfftconv/bigfft.py), exactly as
  * reference conv.py:1420-1524 chains butterfly -> inner -> butterfly_ifft.
