@@ -83,7 +83,9 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
         src = os.path.join(CSRC, f)
         out = os.path.join(obj_dir, f + (".s" if want_asm else ".o"))
         if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time):
-            cmd = [hipcc] + flags + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
+            only = os.environ.get("FFC_VARIANT_ONLY")      # tuning builds: extra flags for one translation unit only
+            fl = flags if (not only or f == only) else HIP_FLAGS
+            cmd = [hipcc] + fl + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -124,7 +126,10 @@ if __name__ == "__main__":
     force = "--force" in sys.argv
     if "--variant" in sys.argv:      # python build.py --variant NAME -DFFC_X=1 ...
         name = sys.argv[sys.argv.index("--variant") + 1]
-        extra = [a for a in sys.argv[1:] if a.startswith("-D") or a.startswith("-m")]
+        extra = []
+        for a in sys.argv[1:]:
+            if a.startswith("-D") or a.startswith("-m"):
+                extra += a.split("=", 1) if a.startswith("-mllvm=") else [a]      # -mllvm=--flag -> -mllvm --flag
         print(build_hip(force, verbose=False, variant=name, extra_flags=extra))
     else:
         print(build_all(force, verbose=True))

@@ -56,11 +56,12 @@ extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B
 // complex output (pair-plane tensor (2, H, N) bf16) instead of dk: first step of dk for big FFT sizes
 extern "C" int ffc_kernel_ifft_grad_c(const ffc_plan* p, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream) {
   if (!p || !ws || !outpair) return ffc_fail("null arg");
-  if (p->hp.N1 <= 1 || p->hp.R > 1) return ffc_fail("ffc_kernel_ifft_grad_c: inner size must be one of 4096 .. 32768");
+  if (p->hp.N1 <= 1) return ffc_fail("ffc_kernel_ifft_grad_c: inner size must be >= 4096");
   int nchunk, ppc;
   ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc);
   DkArgs a{};
   a.ws = (const float*)ws; a.outpair = outpair; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = p->hp.N;
   a.nslab = nchunk * ffc_slabs_per_chunk(p); a.scale = scale; a.s_inv = (float)p->hp_bf.s_inv; a.fast = 1;
+  a.R = p->hp.R;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }

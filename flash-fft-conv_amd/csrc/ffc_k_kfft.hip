@@ -35,8 +35,9 @@ extern "C" int ffc_kernel_fft(const ffc_plan* p, const float* k, int64_t H, int6
 // complex input (pair-plane tensor (2, H, N) dtype) instead of real k: inner k_f rows of big FFT sizes
 extern "C" int ffc_kernel_fft_c(const ffc_plan* p, const void* xpair, int64_t H, void* kf, float scale, void* stream) {
   if (!p || !xpair || !kf) return ffc_fail("null arg");
-  if (p->hp.N1 <= 1 || p->hp.R > 1) return ffc_fail("ffc_kernel_fft_c: inner size must be one of 4096 .. 32768");
+  if (p->hp.N1 <= 1) return ffc_fail("ffc_kernel_fft_c: inner size must be >= 4096");
   KfArgs a{};
   a.xpair = xpair; a.kf = kf; a.tab = p->d_blob; a.t = p->hp.tabs; a.H = (int)H; a.Lk = p->hp.N; a.scale = scale; a.prescale = 1.f; a.s_fwd = (float)p->hp.s_fwd; a.fast = 1;
+  a.R = p->hp.R;
   return ffc_dispatch<KfLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
 }

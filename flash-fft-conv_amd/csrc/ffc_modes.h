@@ -207,7 +207,13 @@ struct Modes : Body<B, GEO, DT> {
         for (int k0 = 0; k0 < a.R; k0++) {
           const Pass ps = make_pass(a.tab, a.t, a.R, k0);
           if (act) {
-            k_rows_in_rp(a, unit_id, un, ps);
+            if (a.xpair) {       // complex input (pair-plane tensor (2, H, R*M)): inner k_f rows of the big FFT sizes
+              ConvArgs cv{};
+              cv.u = a.xpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N * a.R; cv.fast = 1; cv.sbu = (int64_t)a.H * cv.L;
+              BD::template rows_in_rp<BD::NCH>(cv, unit_id, 0, un, ps);
+            } else {
+              k_rows_in_rp(a, unit_id, un, ps);
+            }
             B::lds_fence();
             BD::template outer_stage<true, false, true>(a.Lk, un, a.s_fwd, ps);
           }
@@ -1003,7 +1009,13 @@ struct Modes : Body<B, GEO, DT> {
           if (act) {
             BD::template outer_stage<false, false, true>(a.Lk, un, 1.0f, ps);
             B::lds_fence();
-            dk_rows_out_rp(a, unit_id, un, ps);
+            if (a.outpair) {     // complex output (pair-plane tensor (2, H, R*M) dtype) accumulated over the passes
+              ConvArgs cv{};
+              cv.y = a.outpair; cv.B = 2; cv.H = a.H; cv.L = GEO::N * a.R; cv.fast = 1; cv.sby = (int64_t)a.H * cv.L;
+              BD::template rows_out_rp<BD::NCH>(cv, unit_id, 0, un, ps);
+            } else {
+              dk_rows_out_rp(a, unit_id, un, ps);
+            }
           }
           B::barrier();
         }

@@ -477,6 +477,7 @@ int ffcsim_kernel_fft_c(int N, int dtype, const void* xpair, int H, void* kf, fl
   if (!build_plan(N, dtype, &p)) return -1;
   KfArgs a{};
   a.xpair = xpair; a.kf = kf; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.scale = scale; a.prescale = 1.f; a.s_fwd = (float)p.s_fwd; a.fast = 1;
+  a.R = p.R;
   return dispatch<KfRun>(N, dtype, a);
 }
 
@@ -547,6 +548,7 @@ int ffcsim_kernel_ifft_grad_c(int N, const float* ws, int nslab, int H, void* ou
   if (!build_plan(N, DT_BF16, &p)) return -1;
   DkArgs a{};
   a.ws = ws; a.outpair = outpair; a.tab = p.blob.data(); a.t = p.tabs; a.H = H; a.Lk = N; a.nslab = nslab; a.scale = scale; a.s_inv = (float)p.s_inv; a.fast = 1;
+  a.R = p.R;
   return dispatch<DkRun>(N, DT_BF16, a);
 }
 

@@ -8,16 +8,21 @@ monarch -> butterfly_ifft chain (flashfftconv/conv.py:692-1732, :1867-2002, :334
 The functions are written against an `ops` object (GPU: flashfftconv.conv._TorchOps, CPU tests: the
 wave simulator) so the index/scale bookkeeping is verified without a GPU."""
 
-# N -> (outer factors, fused inner size)
+# N -> (outer factors, fused inner size).  Inner sizes 65536 / 131072 are the multi-pass forms of the fused 32768 kernel
+# (csrc/ffc_body.h struct Pass): with them fft 2M / 4M need ONE HBM-level outer pass (factor 32) instead of two.
+# FFC_BIG_2LEVEL=1 restores the round-1 two-level factorisations of 2M / 4M for A/B runs.
+import os as _os
 BIG_FACTORS = {
     65536: ((16,), 4096),
     131072: ((32,), 4096),
     262144: ((16,), 16384),
     524288: ((16,), 32768),
     1048576: ((32,), 32768),
-    2097152: ((16, 16), 8192),
-    4194304: ((16, 16), 16384),
+    2097152: ((32,), 65536),
+    4194304: ((32,), 131072),
 }
+if _os.environ.get("FFC_BIG_2LEVEL", "0") == "1":
+    BIG_FACTORS.update({2097152: ((16, 16), 8192), 4194304: ((16, 16), 16384)})
 
 
 def level_scale(n0):
@@ -26,6 +31,7 @@ def level_scale(n0):
 
 
 def inner_sfwd(M):
+    """the fused plan's forward scale s_fwd = 2^-ceil(log2(M) / 2) (csrc/ffc_plan.cpp)"""
     lg = M.bit_length() - 1
     return 2.0 ** (-((lg + 1) // 2))
 

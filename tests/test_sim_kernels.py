@@ -123,7 +123,8 @@ def test_golden_forward_through_simulator():
         assert np.allclose(y, g["out"], atol=1e-2)      # the reference's own assert (test_flashfftconv.py:83)
 
 
-@pytest.mark.parametrize("N,L,B,gated", [(65536, 32768, 2, False), (131072, 131072, 1, True), (262144, 100004, 3, False)])
+@pytest.mark.parametrize("N,L,B,gated", [(65536, 32768, 2, False), (131072, 131072, 1, True), (262144, 100004, 3, False),
+                                         (2097152, 600000, 1, True)])      # 2M: one outer level (32) around the 2-pass fft 65536
 def test_big_sizes_through_outer_levels(N, L, B, gated):
     """FFT sizes >= 65536: HBM-level outer passes (csrc/ffc_big.h) + fused inner kernel, orchestrated by
     flashfftconv/bigfft.py on the simulator backend; forward (gated / ragged / odd batch) and dk."""
