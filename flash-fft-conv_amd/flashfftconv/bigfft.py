@@ -8,9 +8,11 @@ monarch -> butterfly_ifft chain (flashfftconv/conv.py:692-1732, :1867-2002, :334
 The functions are written against an `ops` object (GPU: flashfftconv.conv._TorchOps, CPU tests: the
 wave simulator) so the index/scale bookkeeping is verified without a GPU."""
 
-# N -> (outer factors, fused inner size).  Inner sizes 65536 / 131072 are the multi-pass forms of the fused 32768 kernel
-# (csrc/ffc_body.h struct Pass): with them fft 2M / 4M need ONE HBM-level outer pass (factor 32) instead of two.
-# FFC_BIG_2LEVEL=1 restores the round-1 two-level factorisations of 2M / 4M for A/B runs.
+# N -> (outer factors, fused inner size).  Inner size 65536 is the 2-pass form of the fused 32768 kernel (csrc/ffc_body.h
+# struct Pass): with it fft 2M needs ONE HBM-level outer pass (factor 32) instead of two (measured, B16 H48 L=1M: forward
+# 156.6 -> 141.4 ms, backward 271 -> 266 ms rescaled to H=768).  The same trick for 4M (32 x the 4-pass fft 131072) re-reads
+# the full-length rows four times and loses to the two-level form (cfg4 forward 1.33 -> 1.53 ms): 4M stays on two levels.
+# FFC_BIG_2LEVEL=1 / FFC_BIG_1LEVEL=1 force the two-level / one-level form of both sizes for A/B runs.
 import os as _os
 BIG_FACTORS = {
     65536: ((16,), 4096),
@@ -19,10 +21,12 @@ BIG_FACTORS = {
     524288: ((16,), 32768),
     1048576: ((32,), 32768),
     2097152: ((32,), 65536),
-    4194304: ((32,), 131072),
+    4194304: ((16, 16), 16384),
 }
 if _os.environ.get("FFC_BIG_2LEVEL", "0") == "1":
     BIG_FACTORS.update({2097152: ((16, 16), 8192), 4194304: ((16, 16), 16384)})
+if _os.environ.get("FFC_BIG_1LEVEL", "0") == "1":
+    BIG_FACTORS.update({2097152: ((32,), 65536), 4194304: ((32,), 131072)})
 
 
 def level_scale(n0):
