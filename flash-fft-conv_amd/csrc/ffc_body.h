@@ -728,6 +728,7 @@ struct Body {
         }
       }
       A16 re0, im0;
+      u32 s0r[8], s0i[8];
 #pragma unroll
       for (int th = 0; th < 2; th++) {
         Op op;
@@ -756,17 +757,45 @@ struct Body {
             apply8(re, im, half, tr, ti);
           }
         }
-        if (th == 0) {
-          re0 = re; im0 = im;
-        } else {
+        if constexpr (!B::LEAN_OUTER) {
+          if (th == 0) {
+            re0 = re; im0 = im;
+          } else {
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
-            const int c = (r & 3) + 8 * (r >> 2);
-            const int s1 = c / GEO::N1, rwc = c % GEO::N1;
-            i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
-            B::lds_w32(off, B::template pack<DT>(re0[r], re[r]));
-            B::lds_w32(off + GEO::PLANE, B::template pack<DT>(im0[r], im[r]));
+            for (int r = 0; r < 16; r++) {
+              if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
+              const int c = (r & 3) + 8 * (r >> 2);
+              const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+              i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+              B::lds_w32(off, B::template pack<DT>(re0[r], re[r]));
+              B::lds_w32(off + GEO::PLANE, B::template pack<DT>(im0[r], im[r]));
+            }
+          }
+        } else {
+          // backward kernels (128-VGPR budget): the first tile waits as 16 packed row pairs instead of 32 fp32 values;
+          // the store words (tile 2tp | tile 2tp+1 of one row) are the 16-bit half merges of the two tiles' row pairs
+          if (th == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              if (!FWD && HALF && q >= 4) continue;
+              s0r[q] = B::template pack<DT>(re[2 * q], re[2 * q + 1]);
+              s0i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+              if (!FWD && HALF && q >= 4) continue;
+              u32 p1r = B::template pack<DT>(re[2 * q], re[2 * q + 1]), p1i = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
+#pragma unroll
+              for (int o = 0; o < 2; o++) {
+                const int r = 2 * q + o;
+                const int c = (r & 3) + 8 * (r >> 2);
+                const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+                i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+                B::lds_w32(off, o ? B::merge_hi(s0r[q], p1r) : B::merge_lo(s0r[q], p1r));
+                B::lds_w32(off + GEO::PLANE, o ? B::merge_hi(s0i[q], p1i) : B::merge_lo(s0i[q], p1i));
+              }
+            }
           }
         }
       }
@@ -777,7 +806,11 @@ struct Body {
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
   template <bool FWD, bool HALF, bool RP = false>
   static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
-    if constexpr (B::LEAN_OUTER) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
+#ifndef FFC_LEAN_TILE
+#define FFC_LEAN_TILE 0
+#endif
+    // backward kernels (128-VGPR budget): the tile-pair form only fits with one K-step of raw rows (half-empty outer digit)
+    if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF))) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
     else outer_stage_pair<FWD, HALF, RP>(L, un, s_fwd, ps);
   }
 

@@ -305,12 +305,18 @@ static void sim_conv_t(const ConvArgs& a) {
         if (a.R > 1) {       // mirrors conv_kernel<..., RP = true>: the passes run one after the other in the same workgroup
           run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
             Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
-            Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
+            if (16 * GEO::Mi >= a.L) Body<SimB, GEO, DT>::template conv_job<true, true>(a, h, c);
+            else Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
           });
           continue;
         }
       }
-      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Body<SimB, GEO, DT>::conv(a, h, c); });
+      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+        if constexpr (GEO::OUTER && GEO::S1 == 1) {       // the launcher's HALF variant
+          if (16 * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
+        }
+        Body<SimB, GEO, DT>::conv(a, h, c);
+      });
     }
 }
 
@@ -351,9 +357,16 @@ template <class GEO, int DT> struct DkfRun {
           if constexpr (GEO::N == 32768) {
             if (d.c.R > 1) {
               Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
-              for (int k0 = 0; k0 < d.c.R; k0++) Modes<SimBO, GEO, DT>::template dkf<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              const bool half = 16 * GEO::Mi >= d.c.L;
+              for (int k0 = 0; k0 < d.c.R; k0++) {
+                if (half) Modes<SimBO, GEO, DT>::template dkf<true, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+                else Modes<SimBO, GEO, DT>::template dkf<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              }
               return;
             }
+          }
+          if constexpr (GEO::OUTER && GEO::S1 == 1) {     // the launcher's HALF variant (L <= N/2, 32-point outer digit)
+            if (16 * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template dkf<true>(d, h, c, h * d.c.nchunk + c); return; }
           }
           Modes<SimBO, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c);
         });
@@ -367,9 +380,16 @@ template <class GEO, int DT> struct BwdRun {
           if constexpr (GEO::N == 32768) {
             if (d.c.R > 1) {
               Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
-              for (int k0 = 0; k0 < d.c.R; k0++) Modes<SimBO, GEO, DT>::template bwd<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              const bool half = 16 * GEO::Mi >= d.c.L;
+              for (int k0 = 0; k0 < d.c.R; k0++) {
+                if (half) Modes<SimBO, GEO, DT>::template bwd<true, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+                else Modes<SimBO, GEO, DT>::template bwd<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+              }
               return;
             }
+          }
+          if constexpr (GEO::OUTER && GEO::S1 == 1) {
+            if (16 * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template bwd<true>(d, h, c, h * d.c.nchunk + c); return; }
           }
           Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c);
         });
