@@ -1,0 +1,22 @@
+# Round-2 measurement pass (run through gpurun from the repo root): the bench line (with the embedded sweep / configs /
+# cpu baseline), rocprofv3 kernel stats of the same command, PMC passes (separate runs per counter group, only
+# --kernel-trace next to --pmc) for the forward and the fused backward kernel of config 2, kernel stats of fft 64K and cfg4.
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_end; mkdir -p $O
+cd $R
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sweep > $O/stats.log 2>&1
+pmc() { drv=$1; name=$2; shift 2; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/$name -o p -- python $R/benchmarks/$drv > $O/$name.log 2>&1; }
+pmc prof_conv.py c1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
+pmc prof_conv.py c2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
+pmc prof_conv.py c3 FETCH_SIZE
+pmc prof_conv.py c4 WRITE_SIZE
+pmc prof_bwd.py b1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
+pmc prof_bwd.py b2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
+pmc prof_bwd.py b3 FETCH_SIZE
+pmc prof_bwd.py b4 WRITE_SIZE
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/f64k -o s -- python $R/benchmarks/prof_one.py 65536 16 768 32768 both > $O/f64k.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4 -o s -- python $R/benchmarks/prof_one.py 4194304 1 16 1048576 both > $O/cfg4.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -o s -- python $R/benchmarks/prof_one.py 16384 8 1024 8192 both gated > $O/cfg3.log 2>&1
+find $O -name "*_kernel_stats.csv" | head; find $O -name "*counter_collection.csv" | head -3

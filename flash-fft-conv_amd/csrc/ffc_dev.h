@@ -179,7 +179,11 @@ struct DevB {
   // v_sin/v_cos run on the transcendental unit; consumers scheduled right behind them (packed f32 math in
   // particular) were observed to read stale operands on gfx950 (timing-dependent 1-3% errors, caught by a
   // run-to-run determinism check).  An opaque asm with wait states orders them conservatively.
+#ifndef FFC_NO_SETTLE
   static FFC_FN void settle(f32& a, f32& b) { asm volatile("s_nop 4" : "+v"(a), "+v"(b)); }
+#else
+  static FFC_FN void settle(f32&, f32&) {}      // hazard experiment (benchmarks/hazard_probe.py): no wait states
+#endif
   static FFC_FN f32 i2f(i32 a) { return (float)a; }
   static FFC_FN f32 cos_rev(f32 x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: argument in revolutions
   static FFC_FN f32 sin_rev(f32 x) { return __builtin_amdgcn_sinf(x); }
