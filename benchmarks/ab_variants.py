@@ -4,6 +4,8 @@ usage: python benchmarks/ab_variants.py base nopk prio ...   ("base" = the produ
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPES = [(32768, 16, 768, 16384), (16384, 16, 768, 8192), (4096, 16, 768, 2048), (32768, 8, 768, 32768)]
+if os.environ.get("AB_SHAPES"):      # e.g. AB_SHAPES="32768,8,768,32768;8192,16,768,8192"
+    SHAPES = [tuple(int(x) for x in t.split(",")) for t in os.environ["AB_SHAPES"].split(";")]
 
 CHILD = r'''
 import os, sys, json, torch

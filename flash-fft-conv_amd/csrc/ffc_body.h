@@ -182,6 +182,9 @@ struct Body {
   }
   // apply a chain8p result to accumulator rows 8*half + {0..7}
   static FFC_FN void apply8(A16& re, A16& im, int half, const F2 (&tr)[4], const F2 (&ti)[4]) {
+#if defined(FFC_EXP_NOTWIDDLE) || (defined(FFC_KO) && (FFC_KO & 1))
+    return;      // timing experiment only: results are wrong
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) B::template cmul2v<false>(re, im, 8 * half + 2 * i, tr[i], ti[i]);
   }
@@ -308,6 +311,9 @@ struct Body {
   // zero-initialised destination: consecutive loads never wait for each other, and the loads of the next pair
   // can stay in flight across phase C.
   static FFC_FN U4 gload8(const uint16_t* base, i32 n, int L, int fast, bool rowok) {
+#if defined(FFC_KO) && (FFC_KO & 2)
+    { U4 z; z.x = B::as_u32(B::i2f(n)); z.y = z.x; z.z = z.x; z.w = z.x; return z; }     // knock-out experiment: no row loads
+#endif
     if (fast) return (STREAM_ROWS && fast == 2) ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
     u32 w[4];
 #pragma unroll
@@ -320,6 +326,9 @@ struct Body {
     return v;
   }
   static FFC_FN void gstore8(uint16_t* base, i32 n, int L, int fast, bool rowok, U4 v) {
+#if defined(FFC_KO) && (FFC_KO & 2)
+    if (B::as_f32(v.x) != B::as_f32(v.x) + 1.0f) return;      // knock-out experiment: (practically) never stores
+#endif
     if (fast) {
       if (STREAM_ROWS && fast == 2) B::g_w128_nt(base, n >> 3, v, (n < L) && rowok);
       else B::g_w128(base, n >> 3, v, (n < L) && rowok);
@@ -347,12 +356,14 @@ struct Body {
   template <int NC> struct RowRegsT { U4 v[NC][2]; };
   using RowRegs = RowRegsT<NCH>;
   // issue the global loads of pair/tile pq (no LDS access): can be overlapped with compute
-  template <int NC>
+  // chunks I0 .. I0+NC-1 of the wave's slice (I0 > 0: the second half of a split prefetch)
+  template <int NC, int I0 = 0>
   static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
-    for (int i = 0; i < NC; i++) {
+    for (int ii = 0; ii < NC; ii++) {
+      const int i = ii + I0;
       i32 idx = lane + i * 64;
       i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
 #pragma unroll
@@ -360,32 +371,33 @@ struct Body {
         if constexpr (GEO::OUTER) {
           // every lane of this chunk is beyond L (wave-uniform: the chunk's first row is a compile-time constant):
           // nothing to fetch, rows_store writes zeros (L <= N/2 on the 16-point-digit sizes skips half the loads)
-          if (fast && ((i * 64) / CPR) * GEO::Mi >= a.L) { X.v[i][pl] = U4{B::uconst(0), B::uconst(0), B::uconst(0), B::uconst(0)}; continue; }
+          if (fast && ((i * 64) / CPR) * GEO::Mi >= a.L) { X.v[ii][pl] = U4{B::uconst(0), B::uconst(0), B::uconst(0), B::uconst(0)}; continue; }
           const int b = 2 * pq + pl;
           const bool ok = b < a.B;
           const int64_t ro = row_off(b, ok, a.sbu, h, a.L);
-          X.v[i][pl] = gload8((const uint16_t*)a.u + ro, row * GEO::Mi + m, a.L, fast, ok);
+          X.v[ii][pl] = gload8((const uint16_t*)a.u + ro, row * GEO::Mi + m, a.L, fast, ok);
         } else {
           i32 b = (row + pq * GEO::G) * 2 + pl;
-          X.v[i][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, a.sbu, m, fast, b < a.B);
+          X.v[ii][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, a.sbu, m, fast, b < a.B);
         }
       }
     }
   }
   // (x) pregate, swizzle, write to E
-  template <int NC>
+  template <int NC, int I0 = 0>
   static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
-    for (int i = 0; i < NC; i++) {
+    for (int ii = 0; ii < NC; ii++) {
+      const int i = ii + I0;
       i32 idx = lane + i * 64;
       i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
       pred sw;
       i32 off = pair_off(row, m, &sw) + un.eb;
 #pragma unroll
       for (int pl = 0; pl < 2; pl++) {
-        U4 v = X.v[i][pl];
+        U4 v = X.v[ii][pl];
         if (fast && GEO::OUTER) {        // masks of the unconditional fast-path loads
           pred ok = ((row * GEO::Mi + m) < a.L) && ((2 * pq + pl) < a.B);
           v.x = B::sel(ok, v.x, B::uconst(0)); v.y = B::sel(ok, v.y, B::uconst(0));
@@ -806,6 +818,9 @@ struct Body {
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
   template <bool FWD, bool HALF, bool RP = false>
   static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
+#if defined(FFC_KO) && (FFC_KO & 8)
+    return;
+#endif
 #ifndef FFC_LEAN_TILE
 #define FFC_LEAN_TILE 0
 #endif
@@ -987,6 +1002,10 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
+#if defined(FFC_KO) && (FFC_KO & 4)
+    for (int rq = 0; rq < 4; rq++) { k.v[rq].x = B::as_u32(B::i2f(c + tau)); k.v[rq].y = k.v[rq].x; k.v[rq].z = k.v[rq].x; k.v[rq].w = k.v[rq].x; }
+    return;
+#endif
     if (a.flags & 2) {      // tuning flag: k_f as a streaming (non-temporal) read
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128_nt(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
@@ -1117,6 +1136,9 @@ struct Body {
   // waves of the workgroup are then free to drift apart, one unit's global loads / stores overlap another's math
   // instead of all eight meeting at every phase boundary.
   static FFC_FN void unit_barrier() {
+#if defined(FFC_KO) && (FFC_KO & 32)
+    B::lds_fence(); return;
+#endif
     if constexpr (GEO::NW > 1) B::barrier();
     else B::lds_fence();
   }
@@ -1131,12 +1153,18 @@ struct Body {
     // phase B retire in order behind them and the tile loop has no registers to spare
     // (profiles/r01_phase_cycles.txt).
     constexpr bool PREFETCH = HALF && !RP;    // full-length rows: 64 row registers on top of phase C would spill
+    // (a split prefetch for the full-length kernels -- first half of the next pair's rows early, second half at the top of
+    // the iteration -- was measured: the 32768 kernel then needs 256 VGPRs + 16 spilled and runs the same, 8192 gains 2-4 %;
+    // not kept)
+    constexpr bool SPLIT = false;
+    constexpr int NCL = NCH / 2;
     // multi-pass sizes: the R passes of a pair run back to back (pair-major), so that the second read of the input rows and
     // the read-modify-write of the output rows find them in L2
     const int npass = RP ? a.R : 1;
     const int iters = ((p1 - p0 + GEO::UPW - 1) / GEO::UPW) * npass;
-    RowRegsT<NC> X;
-    if (PREFETCH && p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X);
+    constexpr int NCX = SPLIT ? NCL : NC;          // chunks held in X across iterations / loaded at the top
+    RowRegsT<NCX> X;
+    if constexpr (PREFETCH || SPLIT) { if (p0 + u < p1) rows_load<NCX, 0>(a, h, p0 + u, un, X); }
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
@@ -1149,9 +1177,14 @@ struct Body {
       if (act) {
         if constexpr (RP) {
           rows_in_rp<NC>(a, h, p, un, ps);
+        } else if constexpr (SPLIT) {
+          RowRegsT<NCL> Xh;
+          rows_load<NCL, NCL>(a, h, p, un, Xh);       // second half: requested now, written to E after the first half
+          rows_store<NCL, 0>(a, h, p, un, X);
+          rows_store<NCL, NCL>(a, h, p, un, Xh);
         } else {
-          if (!PREFETCH) rows_load<NC>(a, h, p, un, X);
-          rows_store<NC>(a, h, p, un, X);
+          if constexpr (!PREFETCH) rows_load<NCX, 0>(a, h, p, un, X);
+          rows_store<NCX, 0>(a, h, p, un, X);
         }
         B::lds_fence();
         FFC_TICK(0)
@@ -1165,6 +1198,9 @@ struct Body {
         // anything the compiler spills would wait behind it.  k_f is prefetched one tile ahead only here.
         InnerRegs R;
         load_inner(R, un);
+#if defined(FFC_KO) && (FFC_KO & 16)
+        if (a.L < 0)
+#endif
         if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2<RP>(a, hk, un.wq * GEO::TPW + tt, R, un, ps);
@@ -1183,7 +1219,7 @@ struct Body {
       FFC_TICK(3)
       unit_barrier();
       FFC_TICK(4)
-      if (PREFETCH && it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X);
+      if constexpr (PREFETCH || SPLIT) { if (it + 1 < iters && p + GEO::UPW < p1) rows_load<NCX, 0>(a, h, p + GEO::UPW, un, X); }
       if (act) {
         outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
         B::lds_fence();
