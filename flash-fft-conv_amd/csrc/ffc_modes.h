@@ -274,6 +274,9 @@ struct Modes : Body<B, GEO, DT> {
     }
   }
   static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im, bool nt = false) {
+#if defined(FFC_KO) && (FFC_KO & 64)
+    return;        // knock-out timing experiment: no spectrum scratch traffic (results wrong)
+#endif
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
 #pragma unroll
@@ -288,6 +291,10 @@ struct Modes : Body<B, GEO, DT> {
   static FFC_FN void z_load(const void* zs, int tau, typename BD::KfRegs& z, bool nt = false) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
+#if defined(FFC_KO) && (FFC_KO & 64)
+    for (int rq = 0; rq < 4; rq++) { z.v[rq].x = B::as_u32(B::i2f(c + tau)); z.v[rq].y = z.v[rq].x; z.v[rq].z = z.v[rq].x; z.v[rq].w = z.v[rq].x; }
+    return;
+#endif
     if (nt) {
 #pragma unroll
       for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
@@ -450,6 +457,9 @@ struct Modes : Body<B, GEO, DT> {
   }
   template <int T>
   static FFC_FN void w_acc_tile(const typename BD::KfRegs& zv, const A16& re, const A16& im) {
+#if defined(FFC_KO) && (FFC_KO & 128)
+    return;        // knock-out timing experiment: no dk_f accumulation
+#endif
     w_acc_quarter<T, 0>(zv.v[0], re, im);
     w_acc_quarter<T, 1>(zv.v[1], re, im);
     w_acc_quarter<T, 2>(zv.v[2], re, im);
