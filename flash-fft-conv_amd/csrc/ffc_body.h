@@ -857,6 +857,25 @@ struct Body {
     }
   }
 
+  // Inner-only multi-pass form (fft 2048 = 2 passes of the 32 x 32 kernel, struct Pass): with m = 32 n2 + n3 the pass
+  // factor W_N^{m k0} = W_{N/32}^{n2 k0} W_N^{n3 k0}: its n2 part rides in the stage-a DFT matrix (and, conjugated, in
+  // the last inverse matrix), its n3 part in the two inner twiddle tables.  Per pass: [Fa | Finv | tw | tw2] in LDS behind
+  // the single-pass tables (HostPlan tabs.ipass, copied by setup_tables_ipass).
+  static constexpr int IPASS_BYTES = 2 * 6144 + 2 * 8192;
+  static constexpr int L_IPASS = GEO::LDS_BYTES;
+  struct InnerPass { Mat Fa, Finv; CT16 tw; int tw2_off; };
+  static FFC_FN void load_inner_pass(InnerPass& ip, int k0) {
+    const int base = L_IPASS + k0 * IPASS_BYTES;
+    lds_mat(ip.Fa, base);
+    lds_mat(ip.Finv, base + 6144);
+    lds_ct16(ip.tw, base + 12288);
+    ip.tw2_off = base + 12288 + 8192;
+  }
+  static FFC_FN void setup_tables_ipass(const uint8_t* tab, const PlanTabs& t, int R) {
+    for (int k0 = 0; k0 < R; k0++) copy_tab(tab + t.ipass[k0], L_IPASS + k0 * IPASS_BYTES, IPASS_BYTES);
+    B::barrier();
+  }
+
   static FFC_FN void load_tile_op(int tau, Op& op, Unit un, const InnerRegs& R) {
     const int trow = tau * (GEO::G * GEO::Mi * 2);
     if (B::HAS_TR) {
@@ -899,17 +918,22 @@ struct Body {
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
   // TWR: inner twiddle table resident in registers (R.tw); false -> re-read from LDS at each use (saves 32
   // VGPRs in the register-heavy backward kernels)
-  template <bool TWR = true>
-  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im) {
+  template <bool TWR = true, bool IP = false>
+  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im, const InnerPass* ip = nullptr) {
     Op op;
     load_tile_op(tau, op, un, R);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
-    cmm<false, true>(re, im, op, R.F2);
-    if constexpr (TWR) {
-      cmul(re, im, R.tw);
+    if constexpr (IP) {
+      cmm<false, true>(re, im, op, ip->Fa);
+      cmul(re, im, ip->tw);
     } else {
-      cmul_lds<false>(re, im, GEO::L_TW);
+      cmm<false, true>(re, im, op, R.F2);
+      if constexpr (TWR) {
+        cmul(re, im, R.tw);
+      } else {
+        cmul_lds<false>(re, im, GEO::L_TW);
+      }
     }
     to_op(re, im, op);
     // stage b: contract n3 (B-form) -> [V'=(sV,k3) regs][U' lanes]
@@ -923,8 +947,9 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  template <bool TWR = true, bool RP = false>
-  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0, Pass ps = Pass()) {
+  template <bool TWR = true, bool RP = false, bool IP = false>
+  static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0, Pass ps = Pass(),
+                              const InnerPass* ip = nullptr) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     Op op;
@@ -938,7 +963,9 @@ struct Body {
     } else {
       cmm<true, true>(re, im, op, R.F2);
     }
-    if constexpr (GEO::TW2_SEP) {
+    if constexpr (IP) {
+      cmul_lds<false>(re, im, ip->tw2_off);
+    } else if constexpr (GEO::TW2_SEP) {
       cmul_lds<false>(re, im, GEO::L_TW2);
     } else if constexpr (TWR) {
       cmul_conj(re, im, R.tw);
@@ -948,7 +975,8 @@ struct Body {
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
-    cmm<true, true>(re, im, op, R.F2);
+    if constexpr (IP) cmm<true, true>(re, im, op, ip->Finv);
+    else cmm<true, true>(re, im, op, R.F2);
     // outer inverse twiddle s_inv * W_N^{-(n2*N3+n3)*k1}, generated on the fly (v_sin/v_cos take
     // revolutions; the integer phase m*k1 mod N is exact), so no table traffic in the tile loop
     if constexpr (GEO::OUTER) {
@@ -1014,9 +1042,10 @@ struct Body {
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
   }
-  static FFC_FN void inner_tile(const ConvArgs& a, int tau, const InnerRegs& R, Unit un, const KfRegs& kf) {
+  template <bool IP = false>
+  static FFC_FN void inner_tile(const ConvArgs& a, int tau, const InnerRegs& R, Unit un, const KfRegs& kf, const InnerPass* ip = nullptr) {
     A16 re, im;
-    tile_fwd(tau, R, un, re, im);
+    tile_fwd<true, IP>(tau, R, un, re, im, ip);
     // (x) k_f
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
@@ -1031,7 +1060,7 @@ struct Body {
         im[r] = x * ki + y * kr;
       }
     }
-    tile_inv(a.s_inv, tau, R, un, re, im);
+    tile_inv<true, false, IP>(a.s_inv, tau, R, un, re, im, 0, Pass(), ip);
   }
 
   // Two tiles processed in lock-step: their chains are independent, so the MFMAs of one tile execute while
@@ -1265,6 +1294,29 @@ struct Body {
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
       InnerRegs R;
       load_inner(R, un);
+      if constexpr (RP) {
+        // multi-pass inner-only form (fft 2048 on the 32 x 32 kernel): G == 1, the R passes of a pair back to back
+        static_assert(GEO::G == 1, "inner-only multi-pass: one pair per tile");
+#pragma unroll 1
+        for (int it = 0; it < iters * a.R; it++) {
+          const int q = q0 + (it / a.R) * GEO::UPW + u;
+          const int k0 = it % a.R;
+          if (q < q1) {
+            Pass ps; ps.k0 = k0; ps.R = a.R;
+            InnerPass ip;
+            load_inner_pass(ip, k0);
+            KfRegs kf;
+            load_kf(a, h * a.R + k0, 0, kf);
+            rows_in_rp<NCH>(a, h, q, un, ps);
+            B::lds_fence();
+            inner_tile<true>(a, 0, R, un, kf, &ip);
+            B::lds_fence();
+            rows_out_rp<NCH>(a, h, q, un, ps);
+            B::lds_fence();
+          }
+        }
+        return;
+      }
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int q = q0 + it * GEO::UPW + u;

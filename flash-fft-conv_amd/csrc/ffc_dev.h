@@ -340,6 +340,7 @@ static int ffc_dispatch(int N, int dtype, A&&... args) {
     FFC_CASE(256, 1, 16, 16)
     FFC_CASE(512, 1, 16, 32)
     FFC_CASE(1024, 1, 32, 32)
+    FFC_CASE(2048, 1, 32, 32)          // 2 passes of the 1024 kernel (inner-only multi-pass form, Body::InnerPass)
     FFC_CASE(4096, 16, 16, 16)
     FFC_CASE(8192, 32, 16, 16)
     FFC_CASE(16384, 16, 32, 32)

@@ -79,7 +79,7 @@ int ffc_plan_create(int64_t fft_size, int dtype, ffc_plan** out) {
   ffc_plan* p = new ffc_plan();
   if (!build_plan((int)fft_size, dtype, &p->hp)) {
     delete p;
-    return fail("unsupported fft_size/dtype (supported: 256,512,1024,4096,8192,16384,32768,65536,131072; bf16/fp16)");
+    return fail("unsupported fft_size/dtype (supported: 256,512,1024,2048,4096,8192,16384,32768,65536,131072; bf16/fp16)");
   }
   hipError_t e = hipMalloc((void**)&p->d_blob, p->hp.blob.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_blob, p->hp.blob.data(), p->hp.blob.size(), hipMemcpyHostToDevice);

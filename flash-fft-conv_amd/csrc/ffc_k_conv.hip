@@ -35,12 +35,14 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_rp_kernel(ConvArgs a) {
   int h, chunk;
   if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
   BD::setup_tables(a.tab, a.t);
+  if constexpr (!GEO::OUTER) BD::setup_tables_ipass(a.tab, a.t, a.R);     // inner-only form (fft 2048): per-pass tables
   BD::template conv_job<HALF, true>(a, h, chunk);
 }
 
 template <class GEO, int DT>
 struct ConvLaunch {
   static int run(const ConvArgs& a, hipStream_t st) {
+    using BD = Body<DevB, GEO, DT>;
     int hpad = (a.H + 7) & ~7;
     int grid = hpad * a.nchunk;
     if (a.R > 1) {
@@ -54,6 +56,13 @@ struct ConvLaunch {
           if (rc) return rc;
           hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
         }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
+      } else if constexpr (GEO::N == 1024) {
+        constexpr int lds = GEO::LDS_BYTES + 4 * BD::IPASS_BYTES;
+        static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else {

@@ -64,16 +64,19 @@ struct DkfLaunch {
         }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("dkf_rp_kernel launch: ") + hipGetErrorString(e));
-      } else {
+      } else if constexpr (GEO::OUTER) {
         return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       }
     }
     if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
     const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
-      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES);
+      using BD = Body<DevB, GEO, DT>;        // inner-only multi-pass form (fft 2048): per-pass tables behind the plan tables
+      const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
+      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES + 4 * BD::IPASS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, GEO::LDS_BYTES, st, d);
+      if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
+      hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, lds, st, d);
     } else {
       bool half = false;
       if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;
@@ -135,16 +138,19 @@ struct BwdLaunch {
         }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_rp_kernel launch: ") + hipGetErrorString(e));
-      } else {
+      } else if constexpr (GEO::OUTER) {
         return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       }
     }
     if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
     const dim3 grid(ngrid), block(GEO::WGW * 64);
     if constexpr (!GEO::OUTER) {
-      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES);
+      using BD = Body<DevB, GEO, DT>;
+      const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
+      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 4 * BD::IPASS_BYTES);
       if (rc) return rc;
-      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, GEO::LDS_BYTES, st, d);
+      if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
+      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, lds, st, d);
     } else {
       bool half = false;
       if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;

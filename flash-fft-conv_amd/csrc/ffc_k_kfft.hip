@@ -9,10 +9,12 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void kfft_kernel(KfArgs a) {
 template <class GEO, int DT>
 struct KfLaunch {
   static int run(const KfArgs& a, hipStream_t st) {
-    static int rc = ffc_set_lds(kfft_kernel<GEO, DT>, GEO::LDS_BYTES);
+    using BD = Body<DevB, GEO, DT>;
+    const int lds = GEO::LDS_BYTES + ((!GEO::OUTER && a.R > 1) ? a.R * BD::IPASS_BYTES : 0);   // inner-only multi-pass tables
+    static int rc = ffc_set_lds(kfft_kernel<GEO, DT>, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 4 * BD::IPASS_BYTES));
     if (rc) return rc;
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
-    hipLaunchKernelGGL((kfft_kernel<GEO, DT>), dim3((nunits + GEO::UPW - 1) / GEO::UPW), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((kfft_kernel<GEO, DT>), dim3((nunits + GEO::UPW - 1) / GEO::UPW), dim3(GEO::WGW * 64), lds, st, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : ffc_fail(std::string("kfft_kernel launch: ") + hipGetErrorString(e));
   }

@@ -75,6 +75,7 @@ struct Modes : Body<B, GEO, DT> {
   using Unit = typename BD::Unit;
   using Op = typename BD::Op;
   using InnerRegs = typename BD::InnerRegs;
+  using InnerPass = typename BD::InnerPass;
   static FFC_FN Pass make_pass(const uint8_t* tab, const PlanTabs& t, int R, int k0) {
     Pass ps;
     ps.k0 = k0; ps.R = R; ps.mat_fwd = tab + t.matk[k0][0]; ps.mat_inv = tab + t.matk[k0][1];
@@ -188,6 +189,20 @@ struct Modes : Body<B, GEO, DT> {
       }
     }
   }
+  // one 1024-point tile of k_f row `hrow` (G == 1 geometries: the tile is the row; same layout as the OUTER branch of kf_store)
+  static FFC_FN void kf_store_flat(const KfArgs& a, int hrow, const A16& re, const A16& im, int hlim) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      U4 v;
+      v.x = B::template pack<DT>(re[4 * rq] * a.scale, im[4 * rq] * a.scale);
+      v.y = B::template pack<DT>(re[4 * rq + 1] * a.scale, im[4 * rq + 1] * a.scale);
+      v.z = B::template pack<DT>(re[4 * rq + 2] * a.scale, im[4 * rq + 2] * a.scale);
+      v.w = B::template pack<DT>(re[4 * rq + 3] * a.scale, im[4 * rq + 3] * a.scale);
+      B::g_w128(a.kf, ((hi + 2 * rq) * 32 + c) + hrow * 256, v, (c * 0 + hrow) < hlim);
+    }
+  }
   // one workgroup: UPW units (heads, or tiles of G heads)
   static FFC_FN void kfft(const KfArgs& a, int wg) {
     BD::setup_tables(a.tab, a.t);
@@ -251,6 +266,25 @@ struct Modes : Body<B, GEO, DT> {
           A16 re, im;
           BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
           kf_store(a, unit_id, un.wq * GEO::TPW + tt, re, im);
+        }
+      }
+    } else if (a.R > 1) {
+      // inner-only multi-pass form (fft 2048 on the 32 x 32 kernel, BD::InnerPass): k_f rows (head, k0)
+      if constexpr (GEO::N == 1024) {
+        BD::setup_tables_ipass(a.tab, a.t, a.R);
+        if (act) {
+#pragma unroll 1
+          for (int k0 = 0; k0 < a.R; k0++) {
+            Pass ps; ps.k0 = k0; ps.R = a.R;
+            InnerPass ip;
+            BD::load_inner_pass(ip, k0);
+            k_rows_in_rp(a, unit_id, un, ps);
+            B::lds_fence();
+            A16 re, im;
+            BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+            kf_store_flat(a, unit_id * a.R + k0, re, im, a.H * a.R);
+            B::lds_fence();
+          }
         }
       }
     } else {
@@ -643,6 +677,40 @@ struct Modes : Body<B, GEO, DT> {
         BD::unit_barrier();
       }
       w_acc_finish(slab, u, un, W);
+    } else if (a.R > 1) {
+      // inner-only multi-pass form: pass-major (one fp32 W tile in registers per pass), slab rows (head, k0)
+      if constexpr (GEO::N == 1024) {
+        BD::setup_tables_ipass(a.tab, a.t, a.R);
+        const int q0 = p0, q1 = p1;
+        const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
+        BD::load_inner(R, un);
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.R; k0++) {
+          Pass ps; ps.k0 = k0; ps.R = a.R;
+          InnerPass ip;
+          BD::load_inner_pass(ip, k0);
+          A16 wre = B::a16_zero(), wim = B::a16_zero();
+#pragma unroll 1
+          for (int it = 0; it < iters; it++) {
+            const int q = q0 + it * GEO::UPW + u;
+            if (q < q1) {
+              ZReg zv;
+              A16 re, im;
+              BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
+              B::lds_fence();
+              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              z_pack(re, im, zv);
+              B::lds_fence();
+              BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
+              B::lds_fence();
+              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              w_add(wre, wim, zv, re, im);
+              B::lds_fence();
+            }
+          }
+          store_w(d.ws + ((((int64_t)chunk * GEO::UPW + u) * a.H + h) * a.R + k0) * 2048, wre, wim);
+        }
+      }
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
@@ -812,6 +880,48 @@ struct Modes : Body<B, GEO, DT> {
         }
       }
       w_acc_finish(slab, u, un, W);
+    } else if (a.R > 1) {
+      // inner-only multi-pass form: pass-major; du / dpregate accumulate over the passes (rows_out_rp)
+      if constexpr (GEO::N == 1024) {
+        BD::setup_tables_ipass(a.tab, a.t, a.R);
+        const int q0 = p0, q1 = p1;
+        const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
+        BD::load_inner(R, un);
+#pragma unroll 1
+        for (int k0 = 0; k0 < a.R; k0++) {
+          Pass ps; ps.k0 = k0; ps.R = a.R;
+          InnerPass ip;
+          BD::load_inner_pass(ip, k0);
+          A16 wre = B::a16_zero(), wim = B::a16_zero();
+#pragma unroll 1
+          for (int it = 0; it < iters; it++) {
+            const int q = q0 + it * GEO::UPW + u;
+            if (q < q1) {
+              ZReg zv;
+              A16 re, im;
+              typename BD::KfRegs kf;
+              BD::load_kf(a, h * a.R + k0, 0, kf);
+              BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
+              B::lds_fence();
+              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              z_pack(re, im, zv);
+              B::lds_fence();
+              BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
+              B::lds_fence();
+              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              w_add(wre, wim, zv, re, im);
+              kf_conj_mul(kf, re, im);
+              B::lds_fence();
+              BD::template tile_inv<true, false, true>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
+              B::lds_fence();
+              BD::template rows_out_rp<BD::NCH>(ao, h, q, un, ps);
+              if (d.dpre) BD::template rows_out_rp<BD::NCH>(ap, h, q, un, ps);
+              B::lds_fence();
+            }
+          }
+          store_w(d.ws + ((((int64_t)chunk * GEO::UPW + u) * a.H + h) * a.R + k0) * 2048, wre, wim);
+        }
+      }
     } else {
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
       const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
@@ -854,6 +964,17 @@ struct Modes : Body<B, GEO, DT> {
     }
   }
 
+  // W += Zd * conj(Zv) (Zv as packed dtype pairs)
+  static FFC_FN void w_add(A16& wre, A16& wim, const ZReg& zv, const A16& re, const A16& im) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      u32 pr = zv.r[r >> 1], pi = zv.i[r >> 1];
+      f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
+      f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
+      wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
+      wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
+    }
+  }
   static FFC_FN void store_w(float* slab, const A16& re, const A16& im) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
@@ -891,7 +1012,7 @@ struct Modes : Body<B, GEO, DT> {
           i32 V = hi * 4 + 8 * rq;
           i32 sV = V / GEO::N3, k3 = V % GEO::N3, sU = c / GEO::N2, k2 = c % GEO::N2;
           i32 hd = sU * GEO::SV + sV + unit_id * GEO::G;
-          pred ok = hd < a.H;
+          pred ok = hd < a.H * hmul;
 #pragma unroll
           for (int su = 0; su < GEO::SU; su++)
 #pragma unroll
@@ -1051,6 +1172,24 @@ struct Modes : Body<B, GEO, DT> {
           BD::rows_out(cv, unit_id, 0, un);
         } else {
           dk_rows_out(a, unit_id, un);
+        }
+      }
+    } else if (a.R > 1) {
+      if constexpr (GEO::N == 1024) {
+        BD::setup_tables_ipass(a.tab, a.t, a.R);
+        if (act) {
+#pragma unroll 1
+          for (int k0 = 0; k0 < a.R; k0++) {
+            Pass ps; ps.k0 = k0; ps.R = a.R;
+            InnerPass ip;
+            BD::load_inner_pass(ip, k0);
+            A16 re, im;
+            w_load(a, unit_id * a.R + k0, 0, re, im, a.R);
+            BD::template tile_inv<true, false, true>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
+            B::lds_fence();
+            dk_rows_out_rp(a, unit_id, un, ps);
+            B::lds_fence();
+          }
         }
       }
     } else {

@@ -78,6 +78,11 @@ bool plan_factors(int N, int* n1, int* n2, int* n3, int* passes) {
     if (passes) *passes = N / 32768;
     return true;
   }
+  if (N == 2048) {                     // 2 passes of the inner-only 32 x 32 kernel
+    *n1 = 1; *n2 = 32; *n3 = 32;
+    if (passes) *passes = 2;
+    return true;
+  }
   switch (N) {
     case 256: *n1 = 1; *n2 = 16; *n3 = 16; return true;
     case 512: *n1 = 1; *n2 = 16; *n3 = 32; return true;
@@ -207,6 +212,27 @@ void build(HostPlan* p) {
     int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
     cis((double)(n3 * k2), GEO::Mi, GEO::OUTER ? 1.0 : p->s_inv, re, im);
   });
+  for (int k0 = 0; k0 < 4; k0++) t.ipass[k0] = 0;
+  if (!GEO::OUTER && p->R > 1) {
+    // inner-only multi-pass form: with m = N3 n2 + n3 the pass factor W_N^{m k0} = W_{N/N3}^{n2 k0} W_N^{n3 k0}; its n2 part
+    // multiplies the stage-a matrix (contraction index) and, conjugated by the kernels' CONJ flag, the last inverse matrix
+    // (output index); its n3 part multiplies the two inner twiddle tables.
+    for (int k0 = 0; k0 < p->R; k0++) {
+      t.ipass[k0] = bl.alloc(2 * 6144 + 2 * 8192);
+      uint8_t* q = p->blob.data() + t.ipass[k0];
+      fill_mat_pass(q, GEO::N2, p->dtype, k0, p->R, false);
+      fill_mat_pass(q + 6144, GEO::N2, p->dtype, k0, p->R, true);
+      const int R = p->R;
+      fill_ctab16(q + 12288, [&](int lane, int r, double* re, double* im) {
+        int k2 = (lane & 31) % GEO::N2, n3 = acc_row(r, lane >> 5) % GEO::N3;
+        cis(-(double)n3 * (k2 * R + k0), (double)GEO::Mi * R, p->s_fwd, re, im);
+      });
+      fill_ctab16(q + 12288 + 8192, [&](int lane, int r, double* re, double* im) {
+        int n3 = (lane & 31) % GEO::N3, k2 = acc_row(r, lane >> 5) % GEO::N2;
+        cis((double)n3 * (k2 * R + k0), (double)GEO::Mi * R, p->s_inv, re, im);
+      });
+    }
+  }
   for (int k0 = 0; k0 < 4; k0++) t.matk[k0][0] = t.matk[k0][1] = t.mat[0];
   for (int k0 = 1; k0 < p->R; k0++)
     for (int inv = 0; inv < 2; inv++) {

@@ -13,6 +13,8 @@ struct PlanTabs {      // byte offsets into the plan blob
   // multi-pass sizes (HostPlan::R > 1): outer-digit operand tables of pass k0, [k0][0] forward, [k0][1] inverse
   // (pass 0 uses mat[0] for both): F[k1][n1] = W_N1^{n1 k1} W_{R N1}^{n1 k0}, see ffc_plan.cpp fill_mat_pass
   int matk[4][2];
+  // inner-only multi-pass sizes (fft 2048 = 2 passes of the 32 x 32 kernel): per pass [Fa | Finv | tw | tw2] (28672 bytes)
+  int ipass[4];
   int total;
 };
 
@@ -28,7 +30,8 @@ struct HostPlan {
   std::vector<int32_t> kf_freq;  // internal position -> natural frequency, NT*1024 entries
 };
 
-// Supported sizes: 256,512,1024 (inner only), 4096,8192,16384,32768 (outer x inner), 65536,131072 (2 / 4 passes of 32768).
+// Supported sizes: 256,512,1024 (inner only), 2048 (2 passes of 1024), 4096,8192,16384,32768 (outer x inner),
+// 65536,131072 (2 / 4 passes of 32768).
 bool plan_factors(int N, int* n1, int* n2, int* n3, int* passes = nullptr);
 bool build_plan(int N, int dtype, HostPlan* out);
 

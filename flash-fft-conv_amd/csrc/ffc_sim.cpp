@@ -311,6 +311,16 @@ static void sim_conv_t(const ConvArgs& a) {
           continue;
         }
       }
+      if constexpr (GEO::N == 1024) {
+        if (a.R > 1) {       // inner-only multi-pass form (fft 2048)
+          run_wg(GEO::WGW, GEO::LDS_BYTES + a.R * Body<SimB, GEO, DT>::IPASS_BYTES, [&]() {
+            Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
+            Body<SimB, GEO, DT>::setup_tables_ipass(a.tab, a.t, a.R);
+            Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
+          });
+          continue;
+        }
+      }
       run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
         if constexpr (GEO::OUTER && GEO::S1 == 1) {       // the launcher's HALF variant
           if (16 * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
@@ -331,6 +341,7 @@ static int dispatch(int N, int dtype, A&&... args) {
     FFC_CASE(256, 1, 16, 16)
     FFC_CASE(512, 1, 16, 32)
     FFC_CASE(1024, 1, 32, 32)
+    FFC_CASE(2048, 1, 32, 32)
     FFC_CASE(4096, 16, 16, 16)
     FFC_CASE(8192, 32, 16, 16)
     FFC_CASE(16384, 16, 32, 32)
@@ -346,14 +357,14 @@ template <class GEO, int DT> struct KfRun {
   static void run(const KfArgs& a) {
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
     for (int wg = 0; wg < (nunits + GEO::UPW - 1) / GEO::UPW; wg++)
-      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::kfft(a, wg); });
+      run_wg(GEO::WGW, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 4 * Body<SimB, GEO, DT>::IPASS_BYTES), [&]() { Modes<SimB, GEO, DT>::kfft(a, wg); });
   }
 };
 template <class GEO, int DT> struct DkfRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+        run_wg(GEO::WGW, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 4 * Body<SimB, GEO, DT>::IPASS_BYTES), [&]() {
           if constexpr (GEO::N == 32768) {
             if (d.c.R > 1) {
               Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
@@ -376,7 +387,7 @@ template <class GEO, int DT> struct BwdRun {
   static void run(const DkfArgs& d) {
     for (int h = 0; h < d.c.H; h++)
       for (int c = 0; c < d.c.nchunk; c++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+        run_wg(GEO::WGW, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 4 * Body<SimB, GEO, DT>::IPASS_BYTES), [&]() {
           if constexpr (GEO::N == 32768) {
             if (d.c.R > 1) {
               Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
@@ -399,7 +410,7 @@ template <class GEO, int DT> struct DkRun {
   static void run(const DkArgs& a) {
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
     for (int wg = 0; wg < (nunits + GEO::UPW - 1) / GEO::UPW; wg++)
-      run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() { Modes<SimB, GEO, DT>::dkifft(a, wg); });
+      run_wg(GEO::WGW, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 4 * Body<SimB, GEO, DT>::IPASS_BYTES), [&]() { Modes<SimB, GEO, DT>::dkifft(a, wg); });
   }
 };
 template <class GEO, int DT> struct UpwGet { static void run(int* out) { *out = GEO::UPW; } };

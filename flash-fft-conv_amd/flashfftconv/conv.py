@@ -22,7 +22,7 @@ FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
 # measured (profiles/r02_multipass.txt) the 2-pass form is 1.4x faster than the HBM level at fft 65536, the 4-pass form
 # re-reads too much and loses to it at fft 131072, so only 65536 is routed here (FFC_MULTIPASS="65536,131072" / "" for A/B)
 import os as _os
-MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "65536,131072").split(",") if x.strip())
+MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "2048,65536,131072").split(",") if x.strip())
 # fft size 2048 has no 16/32-digit factorisation of its own: it runs on the 4096 plan with k periodised,
 # k' = [k_2048 | k_2048].  FFT_4096(k') is 2*FFT_2048(k) on the even bins and 0 on the odd ones, so the 4096-point
 # circular convolution with k' IS the 2048-point circular convolution with k (u occupies <= 2048 samples, the
@@ -326,8 +326,10 @@ class FlashFFTConv(torch.nn.Module):
             raise NotImplementedError(f"seqlen {seqlen} not supported")
         self.seqlen = seqlen
         self._big = seqlen in _big.BIG_FACTORS and seqlen not in MULTIPASS_SEQLENS
-        self._folded = seqlen in FOLDED_SEQLENS
-        self._plan_seqlen = FOLDED_SEQLENS.get(seqlen, seqlen)
+        # fft 2048: 2 passes of the 1024 kernel (multi-pass plan of its own); folded onto the 4096 plan only when 2048 is
+        # taken out of FFC_MULTIPASS (A/B runs)
+        self._folded = seqlen in FOLDED_SEQLENS and seqlen not in MULTIPASS_SEQLENS
+        self._plan_seqlen = FOLDED_SEQLENS.get(seqlen, seqlen) if self._folded else seqlen
         self.dtype = dtype
         self.use_32_butterfly = use_32_butterfly      # no effect, see the class docstring
         self._kf_keep = None        # frequency-sparse mode: keep bins |f| < _kf_keep (set by sparse_conv)

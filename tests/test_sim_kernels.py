@@ -217,3 +217,30 @@ def test_multipass_backward(N, L, B, H, nch, gated, dt):
     Lk = L - 4
     dk2 = S.sim_dk(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), Lk, pre, post, nchunk=nch)
     assert rel(dk2, r[1][:, :Lk]) < 1.5 * TOL[0]
+
+
+# ---------------------------------------------------------------- fft 2048 = 2 passes of the inner-only 32 x 32 kernel
+@pytest.mark.parametrize("L,B,H", [(1024, 3, 2), (2048, 2, 2), (512, 5, 1), (1500, 2, 1), (2, 1, 1)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_fft2048_inner_multipass(L, B, H, dt):
+    N = 2048
+    rng = np.random.default_rng(L + dt)
+    u, g1, g2, d = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    assert rel(S.from_bits(kf, dt), S.from_bits(S.make_kf_internal(k, N, dt), dt).astype(np.float64)) < (8e-3 if dt == 0 else 1e-3)
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf), dt)
+    assert rel(y, O.ref_fft_conv(q(u, dt), k, N)) < TOL[dt]
+    yg = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, S.to_bits(g1, dt), S.to_bits(g2, dt)), dt)
+    assert rel(yg, O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype=NAME[dt])) < TOL[dt]
+    for gated in (False, True):
+        pre = S.to_bits(g1, dt) if gated else None
+        post = S.to_bits(g2, dt) if gated else None
+        du, dpre, dk = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, L, pre, post, 2)
+        r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), k, q(d, dt), N)
+        assert rel(S.from_bits(du, dt), r[0]) < TOL[dt]
+        assert rel(dk, r[1]) < 1.5 * TOL[0]
+        if gated:
+            assert rel(S.from_bits(dpre, dt), r[2]) < TOL[dt]
+        dk2 = S.sim_dk(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), max(L - 4, 1), pre, post, nchunk=1)
+        assert rel(dk2, r[1][:, :max(L - 4, 1)]) < 1.5 * TOL[0]
