@@ -59,7 +59,7 @@ struct ConvLaunch {
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else if constexpr (GEO::N == 1024) {
-        constexpr int lds = GEO::LDS_BYTES + 4 * BD::IPASS_BYTES;
+        constexpr int lds = GEO::LDS_BYTES + 2 * BD::IPASS_BYTES;
         static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);

@@ -73,7 +73,7 @@ struct DkfLaunch {
     if constexpr (!GEO::OUTER) {
       using BD = Body<DevB, GEO, DT>;        // inner-only multi-pass form (fft 2048): per-pass tables behind the plan tables
       const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
-      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES + 4 * BD::IPASS_BYTES);
+      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
       if (rc) return rc;
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, lds, st, d);
@@ -147,7 +147,7 @@ struct BwdLaunch {
     if constexpr (!GEO::OUTER) {
       using BD = Body<DevB, GEO, DT>;
       const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
-      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 4 * BD::IPASS_BYTES);
+      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
       if (rc) return rc;
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, lds, st, d);

@@ -23,7 +23,8 @@ FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
 # re-reads too much and loses to it at fft 131072, so only 65536 is routed here (FFC_MULTIPASS="65536,131072" / "" for A/B)
 import os as _os
 MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "2048,65536,131072").split(",") if x.strip())
-# fft size 2048 has no 16/32-digit factorisation of its own: it runs on the 4096 plan with k periodised,
+# fft size 2048 has no 16/32-digit factorisation of its own.  By default it runs as 2 passes of the 1024 kernel
+# (MULTIPASS_SEQLENS below); the round-1 form, kept for A/B runs (FFC_MULTIPASS without 2048): the 4096 plan with k periodised,
 # k' = [k_2048 | k_2048].  FFT_4096(k') is 2*FFT_2048(k) on the even bins and 0 on the odd ones, so the 4096-point
 # circular convolution with k' IS the 2048-point circular convolution with k (u occupies <= 2048 samples, the
 # L <= N/2 kernel variant).  dk folds back the same way: dk = dk'[:2048] + dk'[2048:].
