@@ -624,6 +624,10 @@ struct Body {
   }
 
   // ------------------------------------------------------------------ phases A / C (outer DFT, in place)
+  // HALF (L <= N/2): E rows n1 >= N1/2 carry no input and their outputs lie beyond L.  c = tile-local row constant
+  // (bit 2 clear; the lane adds 4*hi): the row is dead iff (c mod N1) >= N1/2.
+  static constexpr bool row_dead(int c) { return (c % GEO::N1) >= GEO::N1 / 2; }
+
   // The wave owns columns [wq*128*S1, +128*S1) of every E row: 4 tiles t, lane j <-> column
   // s1*128 + 4j + t.  FWD: rows are n1 (real pair x), result rows k1 with the W_N^{m k1} twiddle.
   // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
@@ -633,7 +637,7 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
-    constexpr int ms_lim = (FWD && HALF) ? 1 : 2;
+    constexpr int ms_lim = (FWD && HALF && GEO::N1 == 32) ? 1 : 2;      // a whole K-step of dead rows (32-point digit)
     // tile-local row R = 4*hi + c (c a compile-time constant with bit 2 clear) -> column set
     // s1 = c / N1 and E row rw = c % N1 + 4*hi.  e_off = row term + swizzled column term, so every
     // access below is (one of S1 lane-dependent bases) + immediate.
@@ -664,7 +668,8 @@ struct Body {
             const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
             const int s1 = c / GEO::N1, rwc = c % GEO::N1;
             i32 off = colt[s1] + rwc * (GEO::Mi * 2);
-            // no length mask: rows_store zero-fills every E row this stage reads (HALF never reads rows >= 16)
+            // no length mask: rows_store zero-fills every E row this stage reads (HALF never reads the dead rows)
+            if (FWD && HALF && row_dead(c)) { vr[hf] = B::uconst(0); vi[hf] = B::uconst(0); continue; }
             vr[hf] = B::lds_r16(off); vi[hf] = B::lds_r16(off + GEO::PLANE);
           }
           op.r[ms][d] = vr[0] | (vr[1] << 16);
@@ -689,7 +694,7 @@ struct Body {
       }
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
+        if (!FWD && HALF && row_dead((r & 3) + 8 * (r >> 2))) continue;   // rows beyond L: never stored
         u32 vr = B::template pack<DT>(re[r], re[r + 1]);
         u32 vi = B::template pack<DT>(im[r], im[r + 1]);
 #pragma unroll
@@ -714,7 +719,7 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
-    constexpr int ms_lim = (FWD && HALF) ? 1 : 2;
+    constexpr int ms_lim = (FWD && HALF && GEO::N1 == 32) ? 1 : 2;      // a whole K-step of dead rows (32-point digit)
     // tile-local row R = 4*hi + c (c a compile-time constant with bit 2 clear) -> column set
     // s1 = c / N1 and E row rw = c % N1 + 4*hi.  e_off = row term + swizzled column term, so every
     // access below is (one of S1 lane-dependent bases) + immediate.
@@ -736,6 +741,7 @@ struct Body {
           const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
           const int s1 = c / GEO::N1, rwc = c % GEO::N1;
           i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+          if (FWD && HALF && row_dead(c)) { rawr[ms][e] = B::uconst(0); rawi[ms][e] = B::uconst(0); continue; }
           rawr[ms][e] = B::lds_r32(off); rawi[ms][e] = B::lds_r32(off + GEO::PLANE);
         }
       }
@@ -775,7 +781,7 @@ struct Body {
           } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-              if (!FWD && HALF && r >= 8) continue;   // rows >= 16 lie beyond L: never stored
+              if (!FWD && HALF && row_dead((r & 3) + 8 * (r >> 2))) continue;   // rows beyond L: never stored
               const int c = (r & 3) + 8 * (r >> 2);
               const int s1 = c / GEO::N1, rwc = c % GEO::N1;
               i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
@@ -789,14 +795,14 @@ struct Body {
           if (th == 0) {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-              if (!FWD && HALF && q >= 4) continue;
+              if (!FWD && HALF && row_dead(((2 * q) & 3) + 8 * ((2 * q) >> 2))) continue;
               s0r[q] = B::template pack<DT>(re[2 * q], re[2 * q + 1]);
               s0i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
             }
           } else {
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-              if (!FWD && HALF && q >= 4) continue;
+              if (!FWD && HALF && row_dead(((2 * q) & 3) + 8 * ((2 * q) >> 2))) continue;
               u32 p1r = B::template pack<DT>(re[2 * q], re[2 * q + 1]), p1i = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
 #pragma unroll
               for (int o = 0; o < 2; o++) {
@@ -825,7 +831,7 @@ struct Body {
 #define FFC_LEAN_TILE 0
 #endif
     // backward kernels (128-VGPR budget): the tile-pair form only fits with one K-step of raw rows (half-empty outer digit)
-    if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF))) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
+    if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF && GEO::N1 == 32))) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
     else outer_stage_pair<FWD, HALF, RP>(L, un, s_fwd, ps);
   }
 
@@ -1287,7 +1293,7 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      outer_jobs<HALF && GEO::S1 == 1, false, RP>(a, h, p0, p1, u, un);
+      outer_jobs<HALF, false, RP>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -71,7 +71,7 @@ struct ConvLaunch {
     }
     if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
-    if (GEO::OUTER && GEO::S1 == 1 && 16 * GEO::Mi >= a.L) {
+    if (GEO::OUTER && (GEO::N1 / 2) * GEO::Mi >= a.L) {
       static int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
       if (rc) return rc;
       hipLaunchKernelGGL((conv_kernel<GEO, DT, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);

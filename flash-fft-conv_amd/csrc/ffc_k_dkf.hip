@@ -78,10 +78,9 @@ struct DkfLaunch {
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, lds, st, d);
     } else {
-      bool half = false;
-      if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;
+      const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
       if (half) {
-        if constexpr (GEO::S1 == 1) {
+        {
           static int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((dkf_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
@@ -152,10 +151,9 @@ struct BwdLaunch {
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, lds, st, d);
     } else {
-      bool half = false;
-      if constexpr (GEO::S1 == 1) half = 16 * GEO::Mi >= d.c.L;
+      const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
       if (half) {
-        if constexpr (GEO::S1 == 1) {
+        {
           static int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);

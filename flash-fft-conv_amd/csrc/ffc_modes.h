@@ -256,7 +256,7 @@ struct Modes : Body<B, GEO, DT> {
           k_rows_in(a, unit_id, un);
         }
         B::lds_fence();
-        if (GEO::S1 == 1 && 16 * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
+        if ((GEO::N1 / 2) * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
         else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
       }
       B::barrier();
@@ -614,7 +614,7 @@ struct Modes : Body<B, GEO, DT> {
   static FFC_FN void dkf(const DkfArgs& d, int h, int chunk, int wg_linear, int k0 = 0, int wv_in = 0) {
     const ConvArgs& a = d.c;
     const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
-    constexpr int NCX = (HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH;
+    constexpr int NCX = HALF ? BD::NCH / 2 : BD::NCH;
     // multi-pass kernels copy the tables and read the wave index once, before their pass loop (nothing derived from the
     // work-item id stays live across the passes: on the 128-VGPR budget it would be parked in an accumulation register)
     if constexpr (!RP) BD::setup_tables(a.tab, a.t);
@@ -647,7 +647,7 @@ struct Modes : Body<B, GEO, DT> {
           if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
           else BD::template rows_in<NCX>(av, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
+          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -664,7 +664,7 @@ struct Modes : Body<B, GEO, DT> {
           if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
           else BD::template rows_in<NCX>(ad, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
+          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -780,7 +780,7 @@ struct Modes : Body<B, GEO, DT> {
     const ConvArgs& a = d.c;
     const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
     const int hk = RP ? h * a.R + k0 : h;          // k_f row of this (head, pass)
-    constexpr int NCX = (HALF && GEO::S1 == 1) ? BD::NCH / 2 : BD::NCH;
+    constexpr int NCX = HALF ? BD::NCH / 2 : BD::NCH;
     // multi-pass kernels copy the tables and read the wave index once, before their pass loop (nothing derived from the
     // work-item id stays live across the passes: on the 128-VGPR budget it would be parked in an accumulation register)
     if constexpr (!RP) BD::setup_tables(a.tab, a.t);
@@ -821,7 +821,7 @@ struct Modes : Body<B, GEO, DT> {
           if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
           else BD::template rows_in<NCX>(av, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
+          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -844,7 +844,7 @@ struct Modes : Body<B, GEO, DT> {
         BD::unit_barrier();
         if (d.dpost) {
           if (act) {
-            BD::template outer_stage<false, HALF && GEO::S1 == 1, RP>(a.L, un, 1.0f, ps);
+            BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
             B::lds_fence();
             if constexpr (RP) BD::template rows_out_rp<NCX>(aq, h, p, un, ps);    // dpost = y * dout
             else BD::template rows_out<NCX>(aq, h, p, un);
@@ -856,7 +856,7 @@ struct Modes : Body<B, GEO, DT> {
           if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
           else BD::template rows_in<NCX>(ad, h, p, un);
           B::lds_fence();
-          BD::template outer_stage<true, HALF && GEO::S1 == 1, RP>(a.L, un, a.s_fwd, ps);
+          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         }
         BD::unit_barrier();
         if (act) {
@@ -868,7 +868,7 @@ struct Modes : Body<B, GEO, DT> {
         }
         BD::unit_barrier();
         if (act) {
-          BD::template outer_stage<false, HALF && GEO::S1 == 1, RP>(a.L, un, 1.0f, ps);
+          BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
           B::lds_fence();
           if constexpr (RP) {
             BD::template rows_out_rp<NCX>(ao, h, p, un, ps);

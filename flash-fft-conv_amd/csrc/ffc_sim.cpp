@@ -322,8 +322,8 @@ static void sim_conv_t(const ConvArgs& a) {
         }
       }
       run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
-        if constexpr (GEO::OUTER && GEO::S1 == 1) {       // the launcher's HALF variant
-          if (16 * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
+        if constexpr (GEO::OUTER) {       // the launcher's HALF variant
+          if ((GEO::N1 / 2) * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
         }
         Body<SimB, GEO, DT>::conv(a, h, c);
       });
@@ -376,8 +376,8 @@ template <class GEO, int DT> struct DkfRun {
               return;
             }
           }
-          if constexpr (GEO::OUTER && GEO::S1 == 1) {     // the launcher's HALF variant (L <= N/2, 32-point outer digit)
-            if (16 * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template dkf<true>(d, h, c, h * d.c.nchunk + c); return; }
+          if constexpr (GEO::OUTER) {     // the launcher's HALF variant (L <= N/2)
+            if ((GEO::N1 / 2) * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template dkf<true>(d, h, c, h * d.c.nchunk + c); return; }
           }
           Modes<SimBO, GEO, DT>::dkf(d, h, c, h * d.c.nchunk + c);
         });
@@ -399,8 +399,8 @@ template <class GEO, int DT> struct BwdRun {
               return;
             }
           }
-          if constexpr (GEO::OUTER && GEO::S1 == 1) {
-            if (16 * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template bwd<true>(d, h, c, h * d.c.nchunk + c); return; }
+          if constexpr (GEO::OUTER) {
+            if ((GEO::N1 / 2) * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template bwd<true>(d, h, c, h * d.c.nchunk + c); return; }
           }
           Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c);
         });
