@@ -10,8 +10,8 @@ SIM_SO = os.path.join(LIB, "libffcsim.so")
 # --amdgpu-mfma-vgpr-form: MFMA results stay in architectural VGPRs; the accumulation registers a0..a127 are
 #   addressed by hand in the backward kernels (dk_f partial sums) and must never be picked by the allocator.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "--amdgpu-mfma-vgpr-form", "-fPIC"]
-AGPR_CHECKED = ["ffc_k_dkf.hip"]     # translation units whose device code is scanned by check_agpr()
-HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_conv1d_t0.hip", "ffc_conv1d_t1.hip", "ffc_conv1d_t2.hip", "ffc_plan.cpp"]
+AGPR_CHECKED = ["ffc_k_dkf.hip", "ffc_k_bwd.hip"]     # translation units whose device code is scanned by check_agpr()
+HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_bwd.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_conv1d_t0.hip", "ffc_conv1d_t1.hip", "ffc_conv1d_t2.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
 
@@ -78,27 +78,31 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "flashfftconv_hip.h")))
 
-    def compile_one(job):
-        f, want_asm = job
+    def compile_one(f):
+        # checked translation units keep the device assembly of the SAME compile (-save-temps=obj) for check_agpr
+        checked = f in AGPR_CHECKED
         src = os.path.join(CSRC, f)
-        out = os.path.join(obj_dir, f + (".s" if want_asm else ".o"))
-        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time):
+        out = os.path.join(obj_dir, f + ".o")
+        asm = os.path.join(obj_dir, os.path.splitext(f)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time) or (checked and not os.path.exists(asm)):
             only = os.environ.get("FFC_VARIANT_ONLY")      # tuning builds: extra flags for one translation unit only
             fl = flags if (not only or f == only) else HIP_FLAGS
-            cmd = [hipcc] + fl + (["-S", "--cuda-device-only"] if want_asm else ["-c"]) + ["-x", "hip", src, "-o", out]
+            cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + ["-c", "-x", "hip", src, "-o", out]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            if want_asm and not os.environ.get("FFC_SKIP_AGPR_CHECK"):      # (knock-out timing builds skip the check)
-                check_agpr(out)
+            subprocess.check_call(cmd, cwd=obj_dir)
+            if checked and not os.environ.get("FFC_SKIP_AGPR_CHECK"):      # (knock-out timing builds skip the check)
+                try:
+                    check_agpr(asm)
+                except Exception:
+                    os.remove(out)          # a failed check must not leave an object the next build would link
+                    raise
             return out, True
         return out, False
 
-    # the checked translation units are compiled twice (object + device assembly for check_agpr), side by side
-    jobs = [(f, False) for f in HIP_SRCS] + [(f, True) for f in AGPR_CHECKED]
-    jobs.sort(key=lambda j: not (j[0] in AGPR_CHECKED or j[0].startswith('ffc_conv1d_t')))          # longest first
+    jobs = sorted(HIP_SRCS, key=lambda f: not (f in AGPR_CHECKED or f == "ffc_k_conv.hip" or f.startswith('ffc_conv1d_t')))   # longest first
     with ThreadPoolExecutor(max_workers=min(10, os.cpu_count() or 4)) as ex:
-        res = [r for r, j in zip(ex.map(compile_one, jobs), jobs) if not j[1]]
+        res = list(ex.map(compile_one, jobs))
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not os.path.exists(hip_so):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hip_so] + objs)
@@ -109,7 +113,9 @@ def build_sim(force=False):
     os.makedirs(LIB, exist_ok=True)
     srcs = [os.path.join(CSRC, f) for f in SIM_SRCS]
     if force or _stale(SIM_SO, srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", SIM_SO] + srcs)
+        # -O0: the simulator is one large translation unit (every kernel mode x 2 backends x 2 dtypes); -O1 took 7.5 min to
+        # compile at the end of round 2 for a test run of 23 s, -O0 takes 50 s for 40 s
+        subprocess.check_call(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", SIM_SO] + srcs)
     return SIM_SO
 
 

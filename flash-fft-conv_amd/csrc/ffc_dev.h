@@ -358,6 +358,7 @@ static int ffc_dispatch(int N, int dtype, A&&... args) {
 // (Modes::w_acc_finish) and write one slab; the single-tile geometries (N <= 1024) write one per unit.
 static inline int ffc_slabs_per_chunk(const ffc_plan* p) { return p->hp.N1 > 1 ? 1 : 8 / p->hp.NW; }
 
+static inline void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk);
 static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* nchunk, int* ppc, bool fwd_only = false) {
   const bool outer = p->hp.N1 > 1;
   int upw = 8 / p->hp.NW;                       // units a workgroup processes per iteration
@@ -394,4 +395,9 @@ static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* n
   }
   *ppc = ipc * pairs_per_iter;
   *nchunk = (npair + *ppc - 1) / *ppc;
+}
+
+// spectrum scratch of the backward kernels: behind the fp32 dk_f slabs of the workspace (ffc_dkf_workspace_bytes)
+static inline void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk) {
+  return (uint8_t*)ws + (int64_t)nchunk * ffc_slabs_per_chunk(p) * H * p->hp.R * p->hp.NT * 2048 * 4;
 }
