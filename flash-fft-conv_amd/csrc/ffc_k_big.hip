@@ -3,7 +3,7 @@
 using namespace ffc;
 
 template <int N0, int DT, bool FWD>
-__global__ __launch_bounds__(512, 2) void big_kernel(BigArgs a) {
+__global__ __launch_bounds__(GeoBig<N0>::WGW * 64, 2) void big_kernel(BigArgs a) {
   BigBody<DevB, N0, DT>::template run<FWD>(a, blockIdx.x);
 }
 
@@ -13,7 +13,7 @@ static int launch_big(const BigArgs& a, hipStream_t st) {
   if (rc) return rc;
   const int64_t nwg = (int64_t)a.npair * a.Hin * (a.Mi / GeoBig<N0>::Mi);
   if (nwg <= 0 || nwg > 2147483647LL) return ffc_fail("outer pass: bad grid");
-  hipLaunchKernelGGL((big_kernel<N0, DT, FWD>), dim3((unsigned)nwg), dim3(512), GeoBig<N0>::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((big_kernel<N0, DT, FWD>), dim3((unsigned)nwg), dim3(GeoBig<N0>::WGW * 64), GeoBig<N0>::LDS_BYTES, st, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : ffc_fail(std::string("big_kernel launch: ") + hipGetErrorString(e));
 }
@@ -27,7 +27,7 @@ extern "C" int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, in
   const ffc_plan* p = n0 == 16 ? plan16 : plan32;
   if (!p || !in || !out) return ffc_fail("null arg");
   if (n0 != p->hp.N1) return ffc_fail("outer pass: plan's outer digit does not match n0");
-  if (Mi % (1024 * (32 / n0))) return ffc_fail("outer pass: Mi must be a multiple of the column block");
+  if (Mi % (n0 == 16 ? GeoBig<16>::Mi : GeoBig<32>::Mi)) return ffc_fail("outer pass: Mi must be a multiple of the column block");
   if (Llong <= 0 || Llong > n0 * Mi) return ffc_fail("outer pass: bad length");
   BigArgs a{};
   a.in = in; a.out = out; a.gate = gate;

@@ -487,11 +487,11 @@ int ffcsim_big_outer(int N0, int dtype, int fwd, const void* in, void* out, cons
   a.in = in; a.out = out; a.gate = gate; a.fmat = p.blob.data() + p.tabs.mat[0];
   a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
   a.fast = (Llong % 8 == 0) && !g_force_slow;
-  const int cols = 1024 * (32 / N0);
+  const int cols = N0 == 16 ? GeoBig<16>::Mi : GeoBig<32>::Mi;
   if (Mi % cols) return -2;
   const int nwg = npair * Hin * (Mi / cols);
   for (int wg = 0; wg < nwg; wg++) {
-#define FFC_BIG(NN, DD, FF) run_wg(8, GeoBig<NN>::LDS_BYTES, [&]() { BigBody<SimB, NN, DD>::template run<FF>(a, wg); })
+#define FFC_BIG(NN, DD, FF) run_wg(GeoBig<NN>::WGW, GeoBig<NN>::LDS_BYTES, [&]() { BigBody<SimB, NN, DD>::template run<FF>(a, wg); })
     if (N0 == 16) { if (dtype == DT_BF16) { if (fwd) FFC_BIG(16, DT_BF16, true); else FFC_BIG(16, DT_BF16, false); }
                     else { if (fwd) FFC_BIG(16, DT_F16, true); else FFC_BIG(16, DT_F16, false); } }
     else { if (dtype == DT_BF16) { if (fwd) FFC_BIG(32, DT_BF16, true); else FFC_BIG(32, DT_BF16, false); }
