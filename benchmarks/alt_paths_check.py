@@ -1,0 +1,31 @@
+"""The alternative factorisations kept behind environment switches (A/B runs) must stay correct:
+   FFC_MULTIPASS=""   fft 2048 folded onto the 4096 plan, fft 65536 / 131072 through an HBM-level outer pass (round-1 paths)
+   FFC_BIG_2LEVEL=1   fft 2M through two outer levels;  FFC_BIG_1LEVEL=1  fft 4M through one level x the 4-pass inner kernel
+Run as a script (the switches are read at import time); prints one line per case and 'alt paths ok' at the end."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "flash-fft-conv_amd"), ROOT]
+import torch
+from flashfftconv import FlashFFTConv
+from oracle.torch_ref import ref_fft_conv
+
+rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+cases = [int(x) for x in sys.argv[1:]] or [2048, 65536, 131072]
+torch.manual_seed(0)
+for N in cases:
+    for gated in (False, True):
+        B, H, L = 3, 4, N // 2
+        mk = lambda: torch.randn(B, H, L, device="cuda").bfloat16().requires_grad_(True)
+        u = mk(); k = (torch.randn(H, L, device="cuda") * 0.05).requires_grad_(True)
+        g = [mk(), mk()] if gated else []
+        c = [t.detach().clone().requires_grad_(True) for t in [u, k] + g]
+        y = FlashFFTConv(N, dtype=torch.bfloat16).cuda()(u, k, *g)
+        ref = ref_fft_conv(c[0] * c[2], c[1], n=N) * c[3] if gated else ref_fft_conv(c[0], c[1], n=N)
+        dy = torch.randn_like(y)
+        gy = torch.autograd.grad(y, [u, k] + g, dy)
+        gr = torch.autograd.grad(ref, c, dy)
+        errs = [rel(y, ref)] + [rel(a, b) for a, b in zip(gy, gr)]
+        tol = 4e-2 if N >= 65536 else 3e-2
+        print(f"N={N} gated={gated} rel-L2 {['%.2e' % e for e in errs]}", flush=True)
+        assert max(errs) < tol, (N, gated, errs)
+print("alt paths ok")

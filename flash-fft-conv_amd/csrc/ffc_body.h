@@ -1191,15 +1191,12 @@ struct Body {
     // (a split prefetch for the full-length kernels -- first half of the next pair's rows early, second half at the top of
     // the iteration -- was measured: the 32768 kernel then needs 256 VGPRs + 16 spilled and runs the same, 8192 gains 2-4 %;
     // not kept)
-    constexpr bool SPLIT = false;
-    constexpr int NCL = NCH / 2;
     // multi-pass sizes: the R passes of a pair run back to back (pair-major), so that the second read of the input rows and
     // the read-modify-write of the output rows find them in L2
     const int npass = RP ? a.R : 1;
     const int iters = ((p1 - p0 + GEO::UPW - 1) / GEO::UPW) * npass;
-    constexpr int NCX = SPLIT ? NCL : NC;          // chunks held in X across iterations / loaded at the top
-    RowRegsT<NCX> X;
-    if constexpr (PREFETCH || SPLIT) { if (p0 + u < p1) rows_load<NCX, 0>(a, h, p0 + u, un, X); }
+    RowRegsT<NC> X;
+    if constexpr (PREFETCH) { if (p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X); }
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
 #pragma unroll 1
@@ -1212,14 +1209,9 @@ struct Body {
       if (act) {
         if constexpr (RP) {
           rows_in_rp<NC>(a, h, p, un, ps);
-        } else if constexpr (SPLIT) {
-          RowRegsT<NCL> Xh;
-          rows_load<NCL, NCL>(a, h, p, un, Xh);       // second half: requested now, written to E after the first half
-          rows_store<NCL, 0>(a, h, p, un, X);
-          rows_store<NCL, NCL>(a, h, p, un, Xh);
         } else {
-          if constexpr (!PREFETCH) rows_load<NCX, 0>(a, h, p, un, X);
-          rows_store<NCX, 0>(a, h, p, un, X);
+          if constexpr (!PREFETCH) rows_load<NC>(a, h, p, un, X);
+          rows_store<NC>(a, h, p, un, X);
         }
         B::lds_fence();
         FFC_TICK(0)
@@ -1254,7 +1246,7 @@ struct Body {
       FFC_TICK(3)
       unit_barrier();
       FFC_TICK(4)
-      if constexpr (PREFETCH || SPLIT) { if (it + 1 < iters && p + GEO::UPW < p1) rows_load<NCX, 0>(a, h, p + GEO::UPW, un, X); }
+      if constexpr (PREFETCH) { if (it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X); }
       if (act) {
         outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
         B::lds_fence();

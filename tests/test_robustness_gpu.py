@@ -16,3 +16,13 @@ def test_script(script, done):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert done in r.stdout, tail
+
+
+@pytest.mark.parametrize("env,sizes", [({"FFC_MULTIPASS": ""}, ["2048", "65536", "131072"]), ({"FFC_BIG_2LEVEL": "1"}, ["2097152"]),
+                                       ({"FFC_BIG_1LEVEL": "1"}, ["4194304"])])
+def test_alternative_factorisations_stay_correct(env, sizes):
+    """the round-1 paths and the measured-slower factorisations stay reachable through environment switches (A/B runs):
+    forward + every gradient against the torch.fft oracle (benchmarks/alt_paths_check.py)"""
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "alt_paths_check.py")] + sizes, capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0 and "alt paths ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
