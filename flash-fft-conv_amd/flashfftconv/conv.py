@@ -165,41 +165,13 @@ class _TorchOps:
         return out
 
 
-_SIDE = {}
-
-
-def _side_stream(device):
-    """one side stream per device: small problems (cfg4: B = 1, H = 16) do not fill the chip with one launch, so the
-    independent chains of a big-size call (k -> k_f next to the outer pass over u; dk_f -> dk next to the du chain) are
-    enqueued on two HIP streams and joined with events.  Large problems saturate the GPU per launch and stay on one stream."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    s = _SIDE.get(idx)
-    if s is None:
-        s = _SIDE[idx] = torch.cuda.Stream(device=device)
-    return s
-
-
-def _overlap(mod, B, H):
-    return ((B + 1) // 2) * H * mod.seqlen <= (1 << 27) and not torch.cuda.is_current_stream_capturing()
-
-
 def _big_forward(mod, u, k, pregate, postgate):
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = _big.BIG_FACTORS[N][1]
-    k32 = k.detach().to(torch.float32).contiguous()
-    if _overlap(mod, B, H):
-        cur, side = torch.cuda.current_stream(u.device), _side_stream(u.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            kf = _big.kernel_fft(ops, dt, N, k32, H, k.shape[-1])
-        x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
-        cur.wait_stream(side)
-        kf.record_stream(cur)
-    else:
-        kf = _big.kernel_fft(ops, dt, N, k32, H, k.shape[-1])
-        x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
+    kf = _big.kernel_fft(ops, dt, N, k.detach().to(torch.float32).contiguous(), H, k.shape[-1])
+    x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
     y = ops.conv(dt, M, x, kf, False)
     out = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate)
@@ -211,38 +183,21 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len):
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = _big.BIG_FACTORS[N][1]
-    ov = _overlap(mod, B, H)
-    cur = torch.cuda.current_stream(u.device)
-    side = _side_stream(u.device) if ov else cur
-    if ov:
-        side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
     xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate)
-    if ov:
-        cur.wait_stream(side)
-        xu.record_stream(cur)
+    xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
     ws = ops.dkf(dt, M, xd, xu)
-    if ov:
-        side.wait_stream(cur)
-        ws.record_stream(side)
-    with torch.cuda.stream(side):
-        dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
+    dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
     yd = ops.conv(dt, M, xd, kf, True)
     du = torch.empty_like(u)
     shared = {}
     _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared)
     if pregate is None:
-        dpre = dpost = None
-    else:
-        dpre = torch.empty_like(u)
-        _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared)
-        yu = ops.conv(dt, M, xu, kf, False)
-        dpost = torch.empty_like(u)
-        _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout)
-    if ov:
-        cur.wait_stream(side)
-        dk.record_stream(cur)
+        return du, dk, None, None
+    dpre = torch.empty_like(u)
+    _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared)
+    yu = ops.conv(dt, M, xu, kf, False)
+    dpost = torch.empty_like(u)
+    _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout)
     return du, dk, dpre, dpost
 
 
