@@ -311,12 +311,12 @@ class FlashFFTConv(torch.nn.Module):
     Differences a caller can observe:
       * `use_32_butterfly` is accepted for signature compatibility and has no effect: in the reference it only selects
         which of two equivalent factorisations (16- or 32-point outer butterfly) an fft size >= 65536 uses
-        (conv.py:262-551); here the factorisation is internal to the plan (flashfftconv/bigfft.py) and the result is
-        the same convolution either way.
+        (conv.py:262-551); here the factorisation is internal to the plan (multi-pass kernels up to 131072,
+        flashfftconv/bigfft.py above) and the result is the same convolution either way.
       * no tables are registered as buffers: `state_dict()` of this module is empty.  Checkpoints saved from the
         reference module carry its DFT / twiddle buffers (`*.f_32_fft`, `*.twiddle_factors_fft_32_1K`, ...); they are
         accepted and discarded on load, so `load_state_dict(strict=True)` of a reference checkpoint works.
-      * one tensor must stay below 2^31 elements (B*H*L, and for fft sizes >= 65536 also 2*ceil(B/2)*H*fft_size, the
+      * one tensor must stay below 2^31 elements (B*H*L, and for fft sizes >= 262144 also 2*ceil(B/2)*H*fft_size, the
         complex intermediate): larger calls raise RuntimeError; split the batch.
       * H % 16 == 0 is NOT required for fft sizes > 32768 (reference README.md:269), L may be any length <= fft size."""
 
