@@ -93,3 +93,23 @@ def test_sharded_product_two_ranks_one_gpu():
     for rank, ok in res:
         bad = [k for k, v in ok.items() if not v]
         assert not bad, (rank, bad)
+
+
+def test_bench_two_ranks_through_the_driver_launch_line():
+    """bench.py under the driver's N > 1 launch (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
+    both ranks on cuda:0 (FFC_BENCH_SAME_GPU) over gloo: one JSON line from rank 0 with the whole-job value, the weak
+    scaling label and the `strong` object of the fixed problem."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FFC_BENCH_SAME_GPU="1", FFC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "seq/s"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 16 * 768 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["strong"]["heads_per_rank"] == 384 and d["strong"]["value"] > 0
+    assert "cpu_baseline" not in d and "sweep" not in d          # rank 0 at N = 1 only
