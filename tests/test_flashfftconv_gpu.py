@@ -283,6 +283,29 @@ def test_ragged_lengths(N, L, Lk):
     assert rel(out, ref) < 2e-2 and rel(u.grad, uc.grad) < 2e-2 and rel(k.grad, kc.grad) < 2e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144])
+def test_bidirectional_filter_fills_the_fft_size(N, dtype):
+    """The M2-BERT callers pass a 2L-tap kernel, k = pad(k_fwd, (0, L)) + pad(flip(k_rev), (L, 0)), to FlashFFTConv(2L)
+    (examples/bert/monarch_mixer_sequence_mixer_flashfftconv.py:141-151): L = N/2 and Lk = N, the taps beyond L act as
+    negative lags of the circular convolution.  Forward, du and the full-length dk against the torch.fft oracle."""
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(11)
+    L, B, H = N // 2, 2, (5 if N <= 32768 else 2)
+    u = torch.randn(B, H, L, device="cuda").to(dtype).requires_grad_(True)
+    decay = torch.exp(-torch.linspace(0, 6, L, device="cuda"))
+    kf_, kr_ = (torch.randn(H, L, device="cuda") * 0.1 * decay for _ in range(2))
+    k = (torch.nn.functional.pad(kf_, (0, L)) + torch.nn.functional.pad(kr_.flip(-1), (L, 0))).requires_grad_(True)
+    uc, kc = u.detach().clone().requires_grad_(True), k.detach().clone().requires_grad_(True)
+    out = FlashFFTConv(N, dtype=dtype).to("cuda")(u, k)
+    ref = ref_fft_conv(uc, kc, n=N)
+    dout = torch.randn_like(out)
+    out.backward(dout); ref.backward(dout.clone())
+    tol = REL[dtype] * (2.0 if N >= 65536 else 1.0)
+    assert k.grad.shape == (H, N)
+    assert rel(out, ref) < tol and rel(u.grad, uc.grad) < tol and rel(k.grad, kc.grad) < max(tol, 1e-2)
+
+
 def test_errors_and_eval_mode():
     from flashfftconv import FlashFFTConv
     conv = FlashFFTConv(1024, dtype=torch.bfloat16).to("cuda")
