@@ -117,7 +117,7 @@ def run(name, dtype=torch.bfloat16):
         model = Encoder(d_model, n_layer, L, form, dtype).cuda().to(dtype).eval()
         with torch.no_grad():
             y = model(u)
-            ms = ev_time(lambda: model(u), 10)
+            ms = min(ev_time(lambda: model(u), 10) for _ in range(3))      # best of 3: a shared box shows 50 % outliers
         outs[form] = y.float()
         diff = ((outs[form] - outs["torch"]).norm() / outs["torch"].norm()).item()
         print(json.dumps({"model": f"m2-bert-{name}", "d_model": d_model, "n_layer": n_layer, "seqlen": L, "batch": B,
