@@ -60,8 +60,19 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream_ptr(device=None):
     """current stream of `device` (default: the current device; the autograd functions run under
-    torch.cuda.device(u.device), so that is the device of the tensors)"""
+    torch.cuda.device(u.device), so that is the device of the tensors) as a raw hipStream_t.
+    torch._C._cuda_getCurrentRawStream is the accessor kernel launchers use (0.3 us); torch.cuda.current_stream() builds a
+    Stream object and costs 5-10 us per call, four times per forward + backward of a short-sequence step."""
     import torch
+    global _raw_stream
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        idx = None if device is None else (device if isinstance(device, int) else torch.device(device).index)
+        return _raw_stream(torch._C._cuda_getDevice() if idx is None else idx)
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
