@@ -882,8 +882,8 @@ struct Body {
     B::barrier();
   }
 
-  static FFC_FN void load_tile_op(int tau, Op& op, Unit un, const InnerRegs& R) {
-    const int trow = tau * (GEO::G * GEO::Mi * 2);
+  static FFC_FN void load_tile_op(int tau, Op& op, Unit un, const InnerRegs& R, int doff = 0) {
+    const int trow = tau * (GEO::G * GEO::Mi * 2) + doff;     // doff: E of the partner unit (inner_tile2x)
     if (B::HAS_TR) {
 #pragma unroll
       for (int ms = 0; ms < 2; ms++)
@@ -911,7 +911,7 @@ struct Body {
             i32 U = hi * 4 + (16 * ms + 8 * (e >> 2) + (e & 3));
             i32 sU = U / GEO::N2, n2 = U % GEO::N2;
             i32 row = sU * GEO::SV + sV + tau * GEO::G;
-            i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3) + un.eb;
+            i32 off = e_off<GEO, i32>(row, n2 * GEO::N3 + n3) + un.eb + doff;
             wr[hf] = B::lds_r16(off);
             wi[hf] = B::lds_r16(off + GEO::PLANE);
           }
@@ -1106,10 +1106,10 @@ struct Body {
       apply8(re, im, half, tr, ti);
     }
   }
-  static FFC_FN void tile_store(int tau, const InnerRegs& R, const A16& re, const A16& im) {
+  static FFC_FN void tile_store(int tau, const InnerRegs& R, const A16& re, const A16& im, int doff = 0) {
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
-      i32 off = R.woff[rq] + tau * (GEO::G * GEO::Mi * 2);
+      i32 off = R.woff[rq] + tau * (GEO::G * GEO::Mi * 2) + doff;
       U2 vr, vi;
       vr.x = B::template pack<DT>(re[4 * rq], re[4 * rq + 1]);
       vr.y = B::template pack<DT>(re[4 * rq + 2], re[4 * rq + 3]);
@@ -1163,6 +1163,75 @@ struct Body {
     tile_store(tauB, R, reB, imB);
   }
 
+  // Cross-unit form (fft 8192 / 16384: two or four units per workgroup): tile tau of TWO units (two pairs of the same head)
+  // in lock-step instead of two tiles of one unit.  Both tiles meet the same k_f tile and the same outer inverse twiddle
+  // W_N^{-m k1}: one k_f load + unpack and one twiddle chain (4 v_sin/v_cos pairs + the chain multiplies) serve both.
+  // R holds the offsets of the first unit of the group, the partner's E lies EBYTES behind it.
+  static FFC_FN void inner_tile2x(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
+    static_assert(GEO::N3 == GEO::N2 && GEO::OUTER && GEO::UPW >= 2, "inner_tile2x: two units per workgroup");
+    constexpr int DB = GEO::EBYTES;
+    KfRegs kf;
+    load_kf(a, h, tau, kf);
+    Op opA, opB;
+    load_tile_op(tau, opA, un, R);
+    load_tile_op(tau, opB, un, R, DB);
+    A16 reA, imA, reB, imB;
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, true>(reA, imA, opA, R.F2);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, true>(reB, imB, opB, R.F2);
+    cmul(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, false>(reA, imA, opA, R.F2);
+    cmul(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, false>(reB, imB, opB, R.F2);
+    // (x) k_f: unpacked once
+    {
+      CT16 k;
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          k.re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+          k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
+        }
+      }
+      k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
+      cmul(reA, imA, k); to_op(reA, imA, opA);
+      reA = B::a16_zero(); imA = B::a16_zero();
+      cmm<true, true>(reA, imA, opA, R.F2);
+      cmul(reB, imB, k); to_op(reB, imB, opB);
+      reB = B::a16_zero(); imB = B::a16_zero();
+      cmm<true, true>(reB, imB, opB, R.F2);
+    }
+    cmul_conj(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<true, true>(reA, imA, opA, R.F2);
+    cmul_conj(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<true, true>(reB, imB, opB, R.F2);
+    // outer inverse twiddle: one chain per accumulator half, applied to both units' tiles
+    {
+      const i32 lane = B::opaque(B::lane());
+      const i32 c = lane & 31, hi = lane >> 5;
+      const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int sV = (16 * half) / GEO::N3;
+        i32 k1 = sUl * GEO::SV + (sV + tau * GEO::G);
+        i32 n30 = hi * 4 + ((16 * half) % GEO::N3);
+        F2 tr[4], ti[4];
+        chain8p(B::mul24(mlane + n30, k1), k1, 1.0f, a.s_inv, tr, ti);
+        apply8(reA, imA, half, tr, ti);
+        apply8(reB, imB, half, tr, ti);
+      }
+    }
+    tile_store(tau, R, reA, imA);
+    tile_store(tau, R, reB, imB, DB);
+  }
+
   // Job loop of the fused sizes.  HALF (32-point outer digit, L <= N/2): only E rows < 16 carry input and
   // only result rows < 16 are stored, so half of the row traffic is skipped and the next pair's rows fit in
   // 32 VGPRs: they are prefetched right after phase A and written to E after rows_out of the current pair.
@@ -1188,6 +1257,11 @@ struct Body {
     // phase B retire in order behind them and the tile loop has no registers to spare
     // (profiles/r01_phase_cycles.txt).
     constexpr bool PREFETCH = HALF && !RP;    // full-length rows: 64 row registers on top of phase C would spill
+#if defined(FFC_NO_CROSS)
+    constexpr bool CROSS = false;
+#else
+    constexpr bool CROSS = !RP && !PROF && !B::LEAN_OUTER && GEO::N3 == GEO::N2 && GEO::NW > 1 && GEO::UPW >= 2;
+#endif
     // (a split prefetch for the full-length kernels -- first half of the next pair's rows early, second half at the top of
     // the iteration -- was measured: the 32768 kernel then needs 256 VGPRs + 16 spilled and runs the same, 8192 gains 2-4 %;
     // not kept)
@@ -1220,7 +1294,24 @@ struct Body {
       }
       unit_barrier();
       FFC_TICK(2)
-      if (act) {
+      if constexpr (CROSS) {
+        // cross-unit phase B (inner_tile2x): units 2g and 2g+1 of the workgroup form a group, its 2 NW waves take two tiles
+        // each -- of BOTH units when the partner is active, of the first unit alone at the ragged end of a chunk
+        const int ug = u >> 1, wl = (u & 1) * GEO::NW + un.wq;
+        const int pA = p0 + it * GEO::UPW + 2 * ug;
+        if (pA < p1) {
+          Unit ua;
+          ua.eb = 2 * ug * GEO::EBYTES; ua.wq = wl;
+          InnerRegs R;
+          load_inner(R, ua);
+          if (pA + 1 < p1) {
+#pragma unroll 1
+            for (int tt = 0; tt < 2; tt++) inner_tile2x(a, hk, wl * 2 + tt, R, ua);
+          } else {
+            inner_tile2<false>(a, hk, wl * 2, R, ua);
+          }
+        }
+      } else if (act) {
         // no long-latency global load may be outstanding while a phase runs: vmcnt retires in order, so
         // anything the compiler spills would wait behind it.  k_f is prefetched one tile ahead only here.
         InnerRegs R;

@@ -35,6 +35,23 @@ def test_conv_fwd(N, dt, padded):
     assert rel(y, O.ref_fft_conv(q(u, dt), k, N)) < TOL[dt]
 
 
+@pytest.mark.parametrize("N,B", [(8192, 5), (8192, 10), (16384, 5), (16384, 2)])
+def test_conv_cross_unit_groups(N, B):
+    """fft 8192 / 16384: phase B runs tile tau of two units (two pairs of a head) in lock-step (Body::inner_tile2x) and falls
+    back to two tiles of one unit when a group's partner unit has no pair left: pair counts 1, 3, 5 leave every combination
+    (both active / first only / group idle) somewhere in the job loop.  Gated, padded, both k_f signs."""
+    rng = np.random.default_rng(N + B)
+    dt, H, L = 0, 2, N // 2
+    u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.make_kf_internal(k, N, dt)
+    y = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, S.to_bits(g1, dt), S.to_bits(g2, dt)), dt)
+    assert rel(y, O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype=NAME[dt])) < TOL[dt]
+    du = S.from_bits(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, conj=1), dt)
+    dref, _ = O.ref_grads(np.zeros_like(u), k, q(u, dt), N)
+    assert rel(du, dref) < TOL[dt]
+
+
 @pytest.mark.parametrize("N", [256, 1024, 4096, 32768])
 @pytest.mark.parametrize("dt", [0, 1])
 def test_conv_gated_and_conj(N, dt):
