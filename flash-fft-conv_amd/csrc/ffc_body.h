@@ -52,6 +52,10 @@ struct ConvArgs {
   // tensors; larger when the tensor is a channel slice of a wider (B, C, L) tensor (FlashHyenaOp: x1, x2, v are slices of the
   // short convolution's (B, 3D, L) output and are read in place)
   int64_t sbu, sbg, sbp, sby;
+  // forward only, optional: the spectrum of every pair (FFT(u * pregate), dtype, internal order, N complex values per
+  // (head, pair): [H][npair][N][2]) is stored here for the backward pass, which then skips its first transform
+  // (ffc_conv_fwd_z / ffc_conv_bwd_z).  Fused single-pass sizes with an outer digit (fft 4096 ... 32768) only.
+  void* zsave;
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -1032,6 +1036,42 @@ struct Body {
   }
 
   struct KfRegs { U4 v[4]; };
+  // A spectrum tile in global memory: (re, im)-interleaved dtype pairs in the k_f tile layout (16-byte accesses, 1 KiB
+  // per wave instruction).  Used for the backward kernels' scratch and for the spectra the forward pass saves.
+  static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im, bool nt = false) {
+#if defined(FFC_KO) && (FFC_KO & 64)
+    return;        // knock-out timing experiment: no spectrum scratch traffic (results wrong)
+#endif
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      U4 v;
+      v.x = B::template pack<DT>(re[4 * rq], im[4 * rq]);         v.y = B::template pack<DT>(re[4 * rq + 1], im[4 * rq + 1]);
+      v.z = B::template pack<DT>(re[4 * rq + 2], im[4 * rq + 2]); v.w = B::template pack<DT>(re[4 * rq + 3], im[4 * rq + 3]);
+      if (nt) B::g_w128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
+      else B::g_w128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
+    }
+  }
+  static FFC_FN void z_load(const void* zs, int tau, KfRegs& z, bool nt = false) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+#if defined(FFC_KO) && (FFC_KO & 64)
+    for (int rq = 0; rq < 4; rq++) { z.v[rq].x = B::as_u32(B::i2f(c + tau)); z.v[rq].y = z.v[rq].x; z.v[rq].z = z.v[rq].x; z.v[rq].w = z.v[rq].x; }
+    return;
+#endif
+    if (nt) {
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+      return;
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
+  }
+  // saved spectrum of pair p of head h (ConvArgs::zsave layout)
+  static FFC_FN uint8_t* z_slot(void* base, int h, int npair, int p) {
+    return (uint8_t*)base + ((int64_t)h * npair + p) * ((int64_t)GEO::N * 4);
+  }
   static FFC_FN void load_kf(const ConvArgs& a, int h, int tau, KfRegs& k) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
@@ -1119,8 +1159,9 @@ struct Body {
       B::lds_w64(off + GEO::PLANE, vi);
     }
   }
-  template <bool RP = false>
-  static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un, Pass ps = Pass()) {
+  // SZ (compile time: phase B must stay one basic block): store both tiles' spectra at zs (ConvArgs::zsave)
+  template <bool RP = false, bool SZ = false>
+  static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un, Pass ps = Pass(), uint8_t* zs = nullptr) {
     static_assert(GEO::N3 == GEO::N2 && GEO::OUTER, "inner_tile2: fused sizes with one inner matrix");
     const int tauB = tauA + 1;
     KfRegs kfA, kfB;
@@ -1142,6 +1183,7 @@ struct Body {
     cmul(reB, imB, R.tw); to_op(reB, imB, opB);
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<false, false>(reB, imB, opB, R.F2);
+    if constexpr (SZ) { z_store(zs, tauA, reA, imA, true); z_store(zs, tauB, reB, imB, true); }     // spectrum kept for the backward pass
     // (x) k_f, inverse stage b
     kf_mul(a, kfA, reA, imA); to_op(reA, imA, opA);
     reA = B::a16_zero(); imA = B::a16_zero();
@@ -1167,7 +1209,8 @@ struct Body {
   // in lock-step instead of two tiles of one unit.  Both tiles meet the same k_f tile and the same outer inverse twiddle
   // W_N^{-m k1}: one k_f load + unpack and one twiddle chain (4 v_sin/v_cos pairs + the chain multiplies) serve both.
   // R holds the offsets of the first unit of the group, the partner's E lies EBYTES behind it.
-  static FFC_FN void inner_tile2x(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un) {
+  template <bool SZ = false>
+  static FFC_FN void inner_tile2x(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un, uint8_t* zsA = nullptr, uint8_t* zsB = nullptr) {
     static_assert(GEO::N3 == GEO::N2 && GEO::OUTER && GEO::UPW >= 2, "inner_tile2x: two units per workgroup");
     constexpr int DB = GEO::EBYTES;
     KfRegs kf;
@@ -1186,6 +1229,7 @@ struct Body {
     cmul(reB, imB, R.tw); to_op(reB, imB, opB);
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<false, false>(reB, imB, opB, R.F2);
+    if constexpr (SZ) { z_store(zsA, tau, reA, imA, true); z_store(zsB, tau, reB, imB, true); }     // spectra kept for the backward pass
     // (x) k_f: unpacked once
     {
       CT16 k;
@@ -1246,7 +1290,7 @@ struct Body {
     if constexpr (GEO::NW > 1) B::barrier();
     else B::lds_fence();
   }
-  template <bool HALF, bool PROF = false, bool RP = false>
+  template <bool HALF, bool PROF = false, bool RP = false, bool SZ = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
     // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
@@ -1304,11 +1348,12 @@ struct Body {
           ua.eb = 2 * ug * GEO::EBYTES; ua.wq = wl;
           InnerRegs R;
           load_inner(R, ua);
+          uint8_t* zA = SZ ? z_slot(a.zsave, h, a.npair, pA) : nullptr;
           if (pA + 1 < p1) {
 #pragma unroll 1
-            for (int tt = 0; tt < 2; tt++) inner_tile2x(a, hk, wl * 2 + tt, R, ua);
+            for (int tt = 0; tt < 2; tt++) inner_tile2x<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
           } else {
-            inner_tile2<false>(a, hk, wl * 2, R, ua);
+            inner_tile2<false, SZ>(a, hk, wl * 2, R, ua, Pass(), zA);
           }
         }
       } else if (act) {
@@ -1321,7 +1366,8 @@ struct Body {
 #endif
         if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2<RP>(a, hk, un.wq * GEO::TPW + tt, R, un, ps);
+          for (int tt = 0; tt < GEO::TPW; tt += 2)
+            inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps, SZ ? z_slot(a.zsave, h, a.npair, p) : nullptr);
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);
@@ -1359,13 +1405,13 @@ struct Body {
   // ------------------------------------------------------------------ workgroup entry: conv
   // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
   // HALF is chosen by the launcher: 32-point outer digit and L <= N/2
-  template <bool HALF = false>
+  template <bool HALF = false, bool SZ = false>
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
     setup_tables(a.tab, a.t);
-    conv_job<HALF>(a, h, chunk);
+    conv_job<HALF, false, SZ>(a, h, chunk);
   }
   // one (head, chunk) job; the tables are already in LDS.  RP: all passes of a multi-pass size
-  template <bool HALF = false, bool RP = false>
+  template <bool HALF = false, bool RP = false, bool SZ = false>
   static FFC_FN void conv_job(const ConvArgs& a, int h, int chunk) {
     const int wv = B::wave();
     Unit un;
@@ -1376,7 +1422,7 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      outer_jobs<HALF, false, RP>(a, h, p0, p1, u, un);
+      outer_jobs<HALF, false, RP, SZ>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -272,6 +272,15 @@ __device__ __forceinline__ bool map_id(int id, int H, int nchunk, int* h, int* c
   *chunk = s % nchunk;
   return *h < H;
 }
+// Start-up stagger (tuning flag bits 4..7 of ConvArgs::flags = s): workgroup b waits ((b / 8) mod 8) * s * 512 cycles before its
+// first global access.  Every workgroup of a launch runs the same phase sequence for the same time, so without it all CUs
+// request their rows in the same instant (a 16 MB burst at the HBM rate = 3.5 us of exposed wait per burst), then all compute.
+__device__ __forceinline__ void stagger_start(int flags) {
+  const int s = (flags >> 4) & 15;
+  if (s == 0) return;
+  const int n = ((blockIdx.x >> 3) & 7) * s;
+  for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(8);
+}
 __device__ __forceinline__ bool map_block(int H, int nchunk, int* h, int* chunk) {
   int id = blockIdx.x;
   int xcd = id & 7, s = id >> 3;

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(12
   } else {
     int h, chunk;
     if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
+    stagger_start(d.c.flags);
     Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
   }
 }
@@ -86,6 +87,20 @@ struct BwdLaunch {
   }
 };
 
+#if defined(FFC_BWD_PROF)
+// profiling variant only (build.py --variant bwdprof -DFFC_BWD_PROF): per-phase s_memtime sums, [workgroup][wave][16]
+static unsigned long long* ffc_bwd_prof_buffer() {
+  static unsigned long long* buf = nullptr;
+  if (!buf && hipMalloc((void**)&buf, 8192 * 8 * 16 * 8) != hipSuccess) buf = nullptr;
+  return buf;
+}
+extern "C" int ffc_debug_bwd_prof(unsigned long long* out_host, int64_t n_words) {
+  unsigned long long* b = ffc_bwd_prof_buffer();
+  if (!b || n_words > 8192 * 8 * 16) return ffc_fail("no profile buffer");
+  return hipMemcpy(out_host, b, n_words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : ffc_fail("copy failed");
+}
+#endif
+
 // Fused backward: du = pregate * corr(dout*postgate, k), dpre = u * corr(...) (nullable, gated only) and the
 // dk_f partial sums in `ws` (same layout as ffc_conv_bwd_dkf; finish with ffc_kernel_ifft_grad).
 extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
@@ -103,11 +118,13 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
 extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                                     void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                                     int64_t sb_post, int64_t sb_y, void* stream);
-extern "C" int ffc_conv_bwd_gated_strided(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
-                                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
-                                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
-                                          int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
+extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H);
+static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                         const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
+                         int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                         int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
+  if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
   if ((uintptr_t)kf & 15) return ffc_fail("k_f must be 16-byte aligned");
@@ -134,10 +151,30 @@ extern "C" int ffc_conv_bwd_gated_strided(const ffc_plan* p, const void* dout, c
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
   d.dpost = p->hp.N1 > 1 ? dpost : nullptr;
+  d.zin = zin;
   if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;
+#if defined(FFC_BWD_PROF)
+  a.prof = ffc_bwd_prof_buffer();
+#endif
   int rc = ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
   if (rc || !dpost || d.dpost) return rc;
   return ffc_conv_fwd_strided(p, u, kf, pregate, dout, dpost, B, H, L, 0, sb_u, sb_pre, sb_dout, sb_dpost, stream);
+}
+extern "C" int ffc_conv_bwd_gated_strided(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
+                                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                                          int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
+  return conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, nullptr, B, H, L, sb_dout, sb_u, sb_pre, sb_post, sb_du,
+                       sb_dpre, sb_dpost, stream);
+}
+// fused backward on the spectra saved by ffc_conv_fwd_z (same B, H, L, u, pregate): the first transform of every pair is skipped
+extern "C" int ffc_conv_bwd_z(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                              const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
+                              int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                              int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
+  if (!zin) return ffc_fail("null spectrum buffer");
+  return conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, sb_dout, sb_u, sb_pre, sb_post, sb_du,
+                       sb_dpre, sb_dpost, stream);
 }
 extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
                                   const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,

@@ -2,7 +2,8 @@
 #include "ffc_dev.h"
 using namespace ffc;
 
-template <class GEO, int DT, bool HALF>
+// SZ: the forward that also stores the pairs' spectra for the backward pass (ConvArgs::zsave; fused sizes with an outer digit)
+template <class GEO, int DT, bool HALF, bool SZ = false>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
 #if defined(FFC_SETPRIO)
@@ -18,12 +19,13 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
     const int total = ((a.H + 7) & ~7) * a.nchunk;
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
       int h, chunk;
-      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF>(a, h, chunk);
+      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF, false, SZ>(a, h, chunk);
     }
   } else {
     int h, chunk;
     if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
-    BD::template conv<HALF>(a, h, chunk);
+    stagger_start(a.flags);
+    BD::template conv<HALF, SZ>(a, h, chunk);
   }
 }
 
@@ -70,6 +72,23 @@ struct ConvLaunch {
       }
     }
     if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
+    if (a.zsave) {
+      if constexpr (GEO::OUTER) {
+        if ((GEO::N1 / 2) * GEO::Mi >= a.L) {
+          static int rc = ffc_set_lds(conv_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_kernel<GEO, DT, true, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        } else {
+          static int rc = ffc_set_lds(conv_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_kernel<GEO, DT, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel (spectrum-saving) launch: ") + hipGetErrorString(e));
+      } else {
+        return ffc_fail("spectrum buffer on a plan without an outer digit");
+      }
+    }
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
     if (GEO::OUTER && (GEO::N1 / 2) * GEO::Mi >= a.L) {
       static int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
@@ -91,9 +110,14 @@ static inline bool ffc_stride_ok(int64_t* sb, int64_t B, int64_t H, int64_t L) {
   return *sb >= H * L && (B - 1) * *sb + H * L < ((int64_t)1 << 31);
 }
 
-extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
-                                    void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
-                                    int64_t sb_post, int64_t sb_y, void* stream) {
+// spectra saved for the backward pass: [H][npair][N] complex values of the plan dtype; 0 = this plan has no such path
+extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
+  if (!p || p->hp.N1 <= 1 || p->hp.R > 1 || B <= 0 || H <= 0) return 0;
+  return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;
+}
+static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
+                         void* y, void* zsave, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                         int64_t sb_post, int64_t sb_y, void* stream) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -107,6 +131,8 @@ extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_y;
   a.conj_kf = conj_kf;
+  a.zsave = zsave;
+  if (zsave && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zsave & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.flags = p->env_flags;
   a.fast = (L % 8 == 0) && !(((uintptr_t)u | (uintptr_t)y | (uintptr_t)pregate | (uintptr_t)postgate) & 15) &&
@@ -117,6 +143,19 @@ extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void
   // every row is read / written exactly once per launch (multi-pass sizes re-read the rows in every pass: plain accesses)
   a.stream = p->env_stream >= 0 ? p->env_stream : (p->hp.R > 1 ? 0 : 1);
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
+}
+
+extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
+                                    void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                                    int64_t sb_post, int64_t sb_y, void* stream) {
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, B, H, L, conj_kf, sb_u, sb_pre, sb_post, sb_y, stream);
+}
+// forward that also stores every pair's spectrum FFT(u * pregate) in `zsave` (ffc_spectrum_bytes) for ffc_conv_bwd_z
+extern "C" int ffc_conv_fwd_z(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
+                              void* zsave, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                              int64_t sb_y, void* stream) {
+  if (!zsave) return ffc_fail("null spectrum buffer");
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
 }
 
 extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,

@@ -42,6 +42,9 @@ struct DkfArgs {
   // scratch for the first spectrum of a pair (dtype, internal order), one N-point slot per (workgroup, unit):
   // written and read back by the same wave, so it only has to survive in L2 (fused sizes >= 4096)
   void* zscratch;
+  // optional (ffc_conv_bwd_z): the spectra FFT(u * pregate) saved by the forward pass (ConvArgs::zsave layout).  The kernel
+  // then skips its first transform of every pair (rows of u, outer stage, two inner stages, scratch round trip).
+  const void* zin;
 };
 
 struct DkArgs {
@@ -307,36 +310,8 @@ struct Modes : Body<B, GEO, DT> {
       z.i[q] = B::template pack<DT>(im[2 * q], im[2 * q + 1]);
     }
   }
-  static FFC_FN void z_store(void* zs, int tau, const A16& re, const A16& im, bool nt = false) {
-#if defined(FFC_KO) && (FFC_KO & 64)
-    return;        // knock-out timing experiment: no spectrum scratch traffic (results wrong)
-#endif
-    const i32 lane = B::opaque(B::lane());
-    const i32 c = lane & 31, hi = lane >> 5;
-#pragma unroll
-    for (int rq = 0; rq < 4; rq++) {
-      U4 v;
-      v.x = B::template pack<DT>(re[4 * rq], im[4 * rq]);         v.y = B::template pack<DT>(re[4 * rq + 1], im[4 * rq + 1]);
-      v.z = B::template pack<DT>(re[4 * rq + 2], im[4 * rq + 2]); v.w = B::template pack<DT>(re[4 * rq + 3], im[4 * rq + 3]);
-      if (nt) B::g_w128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
-      else B::g_w128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c), v, B::ptrue());
-    }
-  }
-  static FFC_FN void z_load(const void* zs, int tau, typename BD::KfRegs& z, bool nt = false) {
-    const i32 lane = B::opaque(B::lane());
-    const i32 c = lane & 31, hi = lane >> 5;
-#if defined(FFC_KO) && (FFC_KO & 64)
-    for (int rq = 0; rq < 4; rq++) { z.v[rq].x = B::as_u32(B::i2f(c + tau)); z.v[rq].y = z.v[rq].x; z.v[rq].z = z.v[rq].x; z.v[rq].w = z.v[rq].x; }
-    return;
-#endif
-    if (nt) {
-#pragma unroll
-      for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128_nt(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
-      return;
-    }
-#pragma unroll
-    for (int rq = 0; rq < 4; rq++) z.v[rq] = B::g_r128(zs, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
-  }
+  using BD::z_store;
+  using BD::z_load;
   // previous partial sums of a tile, issued at the start of the tile so the latency overlaps tile_fwd
   struct WOld { U4 v[4][2]; };
   static FFC_FN void w_load_old(const float* slab, int tau, bool first, WOld& o) {
@@ -562,7 +537,7 @@ struct Modes : Body<B, GEO, DT> {
     B::barrier();
   }
   // end of a chunk (OUTER geometries): `slab` is the chunk's single slab of this head, [chunk][H][NT*2048] floats
-  static FFC_FN void w_acc_finish(float* slab, int u, Unit un, const WAcc& W) {
+  static FFC_FN void w_acc_finish(float* slab, int u, Unit un, WAcc& W) {
     if constexpr (GEO::UPW == 1) {
       w_acc_store(slab, un.wq * GEO::TPW, W);
     } else {
@@ -581,12 +556,12 @@ struct Modes : Body<B, GEO, DT> {
   // accumulator registers are addressed statically.
   template <bool WITH_DX, bool RP = false>
   static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W,
-                               Pass ps = Pass()) {
+                               Pass ps = Pass(), bool z_stream = false) {
 #pragma unroll 1
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
       typename BD::KfRegs zv;
-      z_load(zs, tau, zv, (a.flags & 4) != 0);
+      z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
       typename BD::KfRegs kf;
       if constexpr (WITH_DX) BD::load_kf(a, h, tau, kf);
       A16 re, im;
@@ -749,6 +724,17 @@ struct Modes : Body<B, GEO, DT> {
   // per pair: Z_v = FFT(u*pregate); Z_d = FFT(dout*postgate); W += Z_d conj(Z_v);
   //           dv = iFFT(Z_d conj(k_f)); du = dv * pregate; dpre = dv * u.
   // (reference: kernels_bf16/monarch_cuda_*_bwd_kernel_bf16.h compute the same three transforms)
+  static FFC_FN void z_unpack(const typename BD::KfRegs& z, A16& re, A16& im) {
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {z.v[rq].x, z.v[rq].y, z.v[rq].z, z.v[rq].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+        im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
+      }
+    }
+  }
   static FFC_FN void kf_plain_mul(const typename BD::KfRegs& kf, A16& re, A16& im) {
     typename BD::CT16 k;
 #pragma unroll
@@ -811,65 +797,127 @@ struct Modes : Body<B, GEO, DT> {
       uint8_t* zs = (uint8_t*)d.zscratch + ((int64_t)(wg_linear * GEO::UPW + u)) * (GEO::N * 4);
       WAcc W;
       w_acc_zero(W);
-      // (the forward kernel's early row request does not fit here: no phase has 32 registers to spare on the
-      // 128-VGPR budget, the allocator would overflow into the accumulation registers)
+      // profiling build (-DFFC_BWD_PROF, lib/variants): s_memtime sums per phase, [wg][wave][16] in a.prof
+#if defined(FFC_BWD_PROF)
+      unsigned long long pacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt0 = 0, pt1 = 0;
+#define FFC_BTICK(k) if constexpr (!RP) { pt1 = B::clock(); pacc[k] += pt1 - pt0; pt0 = pt1; }
+#else
+#define FFC_BTICK(k)
+#endif
+      // (round 3: requesting the next rows ahead of the store bursts -- the next pair's u rows before rows_out, the dout rows
+      // before the last scratch store -- needs 32 live registers at points where the allocator, which treats a0..a127 as free
+      // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
+      // DESIGN.md section 7)
+      const bool have_z = !RP && d.zin != nullptr;
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
         const bool act = p < p1;
-        if (act) {
-          if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
-          else BD::template rows_in<NCX>(av, h, p, un);
-          B::lds_fence();
-          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
-        }
-        BD::unit_barrier();
-        if (act) {
-          BD::template load_inner<false>(R, un);
+#if defined(FFC_BWD_PROF)
+        if constexpr (!RP) pt0 = B::clock();
+#endif
+        // saved spectra (d.zin): the pair's first transform is skipped, its spectrum is read from the forward pass's copy
+        const void* zp = have_z ? (const void*)BD::z_slot(const_cast<void*>(d.zin), h, a.npair, act ? p : p0) : (const void*)zs;
+        if (have_z) {
+          if (d.dpost) {
+            // forward output of this pair for dpost: iFFT(Z_u * k_f) into E.  The previous pair's phase C read every E row.
+            BD::unit_barrier();
+            if (act) {
+              BD::template load_inner<false>(R, un);
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt++) {
-            const int tau = un.wq * GEO::TPW + tt;
-            A16 re, im;
-            BD::template tile_fwd<false>(tau, R, un, re, im);
-            z_store(zs, tau, re, im, (a.flags & 4) != 0);
-            if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
-              // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
-              typename BD::KfRegs kf;
-              BD::load_kf(a, hk, tau, kf);
-              kf_plain_mul(kf, re, im);
-              BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
+              for (int tt = 0; tt < GEO::TPW; tt++) {
+                const int tau = un.wq * GEO::TPW + tt;
+                typename BD::KfRegs zv, kf;
+                z_load(zp, tau, zv, true);
+                BD::load_kf(a, hk, tau, kf);
+                A16 re, im;
+                z_unpack(zv, re, im);
+                kf_plain_mul(kf, re, im);
+                BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
+              }
+            }
+            BD::unit_barrier();
+            if (act) {
+              BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
+              B::lds_fence();
+              BD::template rows_out<NCX>(aq, h, p, un);
             }
           }
-        }
-        BD::unit_barrier();
-        if (d.dpost) {
+          FFC_BTICK(5)
           if (act) {
-            BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
+            BD::template rows_in<NCX>(ad, h, p, un);
             B::lds_fence();
-            if constexpr (RP) BD::template rows_out_rp<NCX>(aq, h, p, un, ps);    // dpost = y * dout
-            else BD::template rows_out<NCX>(aq, h, p, un);
+            FFC_BTICK(6)
+            BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+            FFC_BTICK(7)
           }
-          // no barrier: phase C, rows_out and the rows_in / phase A that follow all stay inside the wave's own
-          // column slice of E (same as between two pairs of the forward kernel)
-        }
-        if (act) {
-          if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
-          else BD::template rows_in<NCX>(ad, h, p, un);
-          B::lds_fence();
-          BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+        } else {
+          if (act) {
+            if constexpr (RP) BD::template rows_in_rp<NCX>(av, h, p, un, ps);
+            else BD::template rows_in<NCX>(av, h, p, un);
+            B::lds_fence();
+            FFC_BTICK(0)
+            BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+            FFC_BTICK(1)
+          }
+          BD::unit_barrier();
+          FFC_BTICK(2)
+          if (act) {
+            BD::template load_inner<false>(R, un);
+#pragma unroll 1
+            for (int tt = 0; tt < GEO::TPW; tt++) {
+              const int tau = un.wq * GEO::TPW + tt;
+              A16 re, im;
+              BD::template tile_fwd<false>(tau, R, un, re, im);
+              z_store(zs, tau, re, im, (a.flags & 4) != 0);
+              if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
+                // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
+                typename BD::KfRegs kf;
+                BD::load_kf(a, hk, tau, kf);
+                kf_plain_mul(kf, re, im);
+                BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
+              }
+            }
+          }
+          FFC_BTICK(3)
+          BD::unit_barrier();
+          FFC_BTICK(4)
+          if (d.dpost) {
+            if (act) {
+              BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
+              B::lds_fence();
+              if constexpr (RP) BD::template rows_out_rp<NCX>(aq, h, p, un, ps);    // dpost = y * dout
+              else BD::template rows_out<NCX>(aq, h, p, un);
+            }
+            // no barrier: phase C, rows_out and the rows_in / phase A that follow all stay inside the wave's own
+            // column slice of E (same as between two pairs of the forward kernel)
+          }
+          FFC_BTICK(5)
+          if (act) {
+            if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
+            else BD::template rows_in<NCX>(ad, h, p, un);
+            B::lds_fence();
+            FFC_BTICK(6)
+            BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+            FFC_BTICK(7)
+          }
         }
         BD::unit_barrier();
+        FFC_BTICK(8)
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<true, RP>(a, hk, un, R, zs, slab, it == 0, W, ps);
+          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
         }
+        FFC_BTICK(9)
         BD::unit_barrier();
+        FFC_BTICK(10)
         if (act) {
           BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
           B::lds_fence();
+          FFC_BTICK(11)
           if constexpr (RP) {
             BD::template rows_out_rp<NCX>(ao, h, p, un, ps);
             if (d.dpre) BD::template rows_out_rp<NCX>(ap, h, p, un, ps);
@@ -877,8 +925,18 @@ struct Modes : Body<B, GEO, DT> {
             BD::template rows_out<NCX>(ao, h, p, un);
             if (d.dpre) BD::template rows_out<NCX>(ap, h, p, un);
           }
+          FFC_BTICK(12)
         }
       }
+#if defined(FFC_BWD_PROF)
+      if (!RP && a.prof) {
+        const i32 lane = B::lane();
+        unsigned long long* dst = a.prof + ((long long)wg_linear * GEO::WGW + wv) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) B::g_w64(dst, lane * 0 + k, B::u2_from64(pacc[k]), lane < 1);
+      }
+#endif
+#undef FFC_BTICK
       w_acc_finish(slab, u, un, W);
     } else if (a.R > 1) {
       // inner-only multi-pass form: pass-major; du / dpregate accumulate over the passes (rows_out_rp)

@@ -100,6 +100,27 @@ def _conv(plan, u, kf, pregate, postgate, conj):
     return y
 
 
+def _spectrum_buffer(plan, B, H, device):
+    """Buffer for the spectra FFT(u * pregate) that the forward pass keeps for the backward pass (ffc_conv_fwd_z / ffc_conv_bwd_z),
+    or None: plan without that path (fft < 4096, multi-pass and HBM-level sizes), or no memory for it (the caller then takes the
+    recomputing path, like the reference)."""
+    n = _lib.lib().ffc_spectrum_bytes(plan.handle, B, H)
+    if n <= 0:
+        return None
+    try:
+        return torch.empty(n, dtype=torch.uint8, device=device)
+    except torch.cuda.OutOfMemoryError:
+        return None
+
+
+def _conv_save(plan, u, kf, pregate, postgate, z):
+    B, H, L = u.shape
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate), _lib.ptr(y),
+                                         _lib.ptr(z), B, H, L, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_fwd_z")
+    return y
+
+
 def _kernel_fft(plan, k):
     """k (H, Lk) fp32 -> k_f in the plan's internal order (H, kf_elems, 2), plan dtype."""
     H = k.shape[0]
@@ -250,10 +271,21 @@ class _FlashFFTConvFn(torch.autograd.Function):
                     kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
                 if mod.cache_kf and not k.requires_grad:
                     mod._kf_cache = (_kf_key(k), kf)
-            out = _conv(plan, u, kf, pregate, postgate, False)
+            # MI355X design (memory laid out for 288 GB of HBM): an ungated training forward keeps every pair's spectrum
+            # FFT(u) (2x the bytes of u at L = N/2) so that the backward pass does not transform u a second time: its
+            # kernel runs two transforms per pair instead of three (fused backward -30 % at B16 H768 fft 32768,
+            # profiles/r03_spectrum.txt).  module.save_spectrum = False (or FFC_SAVE_SPECTRUM=0) keeps the reference's
+            # recomputing backward.  Not for the gated form: its backward needs the first spectrum's inverse for dpostgate anyway
+            # and the extra forward store costs what the backward saves.
+            z = None
+            if mod.training and mod.save_spectrum and not ctx.gated and any(ctx.needs_input_grad[:2]):
+                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device)
+            out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             if ctx.gated:
                 ctx.save_for_backward(u, kf, pregate, postgate)
+            elif not ctx.big and z is not None:
+                ctx.save_for_backward(u, kf, z)      # (a saved tensor: released with the graph, kept by retain_graph)
             else:
                 ctx.save_for_backward(u, kf)
         return out
@@ -268,10 +300,12 @@ class _FlashFFTConvFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dout):
         dout = dout.contiguous()
+        z = None
         if ctx.gated:
             u, kf, pregate, postgate = ctx.saved_tensors
         else:
-            (u, kf), pregate, postgate = ctx.saved_tensors, None, None
+            (u, kf), pregate, postgate = ctx.saved_tensors[:2], None, None
+            z = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         if ctx.big:
             du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len)
             return du, dk.to(ctx.k_dtype), None, dpre, dpost
@@ -284,9 +318,14 @@ class _FlashFFTConvFn(torch.autograd.Function):
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
         dpost = torch.empty_like(u) if ctx.gated else None
-        _lib.check(lib.ffc_conv_bwd_gated(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
-                                          _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws),
-                                          B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_gated")
+        if z is not None:
+            _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
+                                          _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws), _lib.ptr(z),
+                                          B, H, L, 0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
+        else:
+            _lib.check(lib.ffc_conv_bwd_gated(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
+                                              _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws),
+                                              B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_gated")
         if ctx.mod._kf_keep is not None:
             # d/dk of (mask * FFT(k)): mask the fp32 dk_f partial sums (same internal order as k_f) before the inverse
             nfl = H * plan.kf_elems * 2
@@ -341,6 +380,8 @@ class FlashFFTConv(torch.nn.Module):
         # that is re-generated into recycled memory every step would look "unchanged".
         self.cache_kf = False
         self._kf_cache = None
+        # training forward keeps FFT(u) for the backward pass (see _FlashFFTConvFn._forward); FFC_SAVE_SPECTRUM=0 turns it off
+        self.save_spectrum = _os.environ.get("FFC_SAVE_SPECTRUM", "1") != "0"
 
     def _cached_kf(self, k):
         c = self._kf_cache

@@ -81,6 +81,21 @@ int ffc_conv_bwd_gated_strided(const ffc_plan* plan, const void* dout, const voi
                                const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
                                int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_du,
                                int64_t sb_dpre, int64_t sb_dpost, void* stream);
+/* Spectrum-saving pair of the two calls above (MI355X design, no reference counterpart: the reference's backward kernels
+ * recompute FFT(u * pregate), kernels_bf16/monarch_cuda_32_32_32_bwd_kernel_bf16.h).  ffc_conv_fwd_z also stores every batch
+ * pair's spectrum FFT(u * pregate) (plan dtype, internal order, ffc_spectrum_bytes() bytes: 2x the size of u at L = N/2) and
+ * ffc_conv_bwd_z reads it instead of transforming u again: one of the backward's three transforms per pair, its rows of u
+ * and its scratch round trip disappear.  du / dpregate come out bit for bit as from ffc_conv_bwd_gated_strided; dk and dpostgate
+ * agree to the rounding of the spectrum (the forward and the backward kernel schedule the same fp32 operations differently).  Fused single-pass sizes with an outer digit only (fft 4096 ... 32768):
+ * ffc_spectrum_bytes() returns 0 for every other plan. */
+int64_t ffc_spectrum_bytes(const ffc_plan* plan, int64_t B, int64_t H);
+int ffc_conv_fwd_z(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
+                   void* zsave, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_y,
+                   void* stream);
+int ffc_conv_bwd_z(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
+                   const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
+                   int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_du, int64_t sb_dpre,
+                   int64_t sb_dpost, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

@@ -1,0 +1,107 @@
+"""Spectrum-saving forward / backward pair (ffc_conv_fwd_z / ffc_conv_bwd_z; include/flashfftconv_hip.h): the training forward
+keeps FFT(u * pregate) and the backward kernel reads it instead of transforming u a second time (the reference recomputes:
+kernels_bf16/monarch_cuda_32_32_32_bwd_kernel_bf16.h).  Checked against the recomputing pair through the C-ABI (y, du,
+dpregate bit for bit; dk, dpostgate to the rounding of the spectrum) and against the torch.fft oracle through the module."""
+import pytest
+import torch
+
+from oracle.torch_ref import ref_fft_conv
+from tests.test_flashfftconv_gpu import rel, make_inputs, stable, REL
+
+pytestmark = pytest.mark.gpu
+SIZES = [4096, 8192, 16384, 32768]
+SHAPES = [(4, 16), (3, 7), (1, 5), (16, 24)]      # (B, H): even, odd batch, single row, several chunks
+
+
+def _call_pair(N, B, H, L, dtype, gated):
+    from flashfftconv import FlashFFTConv, conv as C, _lib
+    lib, P, sp = _lib.lib(), _lib.ptr, _lib.stream_ptr
+    torch.manual_seed(N + 7 * B + H)
+    u = torch.randn(B, H, L, device="cuda").to(dtype); dout = torch.randn(B, H, L, device="cuda").to(dtype)
+    k = torch.randn(H, L, device="cuda") * torch.exp(-0.05 * torch.arange(L, device="cuda")) / 4
+    pre = torch.randn_like(u) if gated else None; post = torch.randn_like(u) if gated else None
+    plan = FlashFFTConv(N, dtype=dtype).cuda()._get_plan(u.device)
+    kf = C._kernel_fft(plan, k)
+    zb = lib.ffc_spectrum_bytes(plan.handle, B, H)
+    assert zb == ((B + 1) // 2) * H * N * 4
+    z = torch.empty(zb, dtype=torch.uint8, device="cuda")
+    ws0 = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda"); ws1 = torch.empty_like(ws0)
+    y0, y1 = torch.full_like(u, 7.0), torch.full_like(u, 9.0)
+    o0 = [torch.full_like(u, 3.0) for _ in range(3)]; o1 = [torch.full_like(u, 5.0) for _ in range(3)]
+    g = (lambda t: P(t)) if gated else (lambda t: None)
+    _lib.check(lib.ffc_conv_fwd(plan.handle, P(u), P(kf), P(pre), P(post), P(y0), B, H, L, 0, sp()), "fwd")
+    _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y1), P(z), B, H, L, 0, 0, 0, 0, sp()), "fwd_z")
+    _lib.check(lib.ffc_conv_bwd_gated(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o0[0]), g(o0[1]), g(o0[2]), P(ws0), B, H, L, sp()), "bwd")
+    _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o1[0]), g(o1[1]), g(o1[2]), P(ws1), P(z), B, H, L,
+                                  0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
+    dk0 = torch.empty(H, L, device="cuda"); dk1 = torch.empty(H, L, device="cuda")
+    _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws0), B, H, L, P(dk0), sp()), "dk")
+    _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws1), B, H, L, P(dk1), sp()), "dk")
+    torch.cuda.synchronize()
+    return (y0, o0, dk0), (y1, o1, dk1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("N", SIZES)
+def test_saved_spectrum_equals_recompute(N, gated, dtype):
+    for (B, H) in SHAPES:
+        for L in (N // 2, N, N // 2 - 8, N - 3):      # padded, full, ragged fast path, ragged slow path (L % 8 != 0)
+            (y0, o0, dk0), (y1, o1, dk1) = _call_pair(N, B, H, L, dtype, gated)
+            tag = f"fft {N} B{B} H{H} L{L} gated={gated} {dtype}"
+            assert torch.equal(y0, y1), f"{tag}: forward output changed by the spectrum store"
+            assert torch.equal(o0[0], o1[0]), f"{tag}: du"
+            # same spectrum up to the last bit of its rounding to the plan dtype (the fp32 schedule of the two kernels differs):
+            # outputs that are rounded once more (dpostgate) move by single steps of the dtype
+            step = 1e-2 if dtype == torch.bfloat16 else 2e-3
+            assert rel(dk1, dk0) < 2e-3, f"{tag}: dk rel {rel(dk1, dk0):.2e}"
+            if gated:
+                assert torch.equal(o0[1], o1[1]), f"{tag}: dpregate"
+                assert rel(o1[2], o0[2]) < step, f"{tag}: dpostgate rel {rel(o1[2], o0[2]):.2e}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", SIZES)
+def test_module_gradients_with_saved_spectrum(N, dtype):
+    """module level: save_spectrum on (default) against the torch.fft oracle and against save_spectrum off."""
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(1)
+    B, H, L = 6, 24, N // 2
+    u, k = make_inputs(B, H, L, N, dtype, False)
+    dout = torch.randn_like(u) * 0.02
+    grads = {}
+    for save in (True, False):
+        conv = FlashFFTConv(N, dtype=dtype).cuda()
+        conv.save_spectrum = save
+        uu, kk = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
+        out = conv(uu, kk)
+        g = torch.autograd.grad(out, (uu, kk), dout, retain_graph=True)
+        g2 = torch.autograd.grad(out, (uu, kk), dout)
+        assert all(torch.equal(a, b) for a, b in zip(g, g2)), "second backward through a retained graph differs"
+        grads[save] = (out.detach(), g)
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1][0], grads[False][1][0])
+    uc, kc = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    (ref,) = stable(lambda: (ref_fft_conv(uc, kc, n=N),), "forward")
+    gref = stable(lambda: torch.autograd.grad(ref, (uc, kc), dout.clone(), retain_graph=True), "backward")
+    out, g = grads[True]
+    assert rel(out, ref) < REL[dtype] and rel(g[0], gref[0]) < REL[dtype]
+    assert rel(g[1], gref[1]) < max(REL[dtype], 1e-2), f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
+    assert rel(grads[False][1][1], gref[1]) < max(REL[dtype], 1e-2)
+
+
+def test_no_spectrum_path_for_other_plans():
+    from flashfftconv import FlashFFTConv, _lib
+    lib = _lib.lib()
+    for N in (256, 1024, 2048, 65536, 131072):
+        plan = FlashFFTConv(N, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
+        assert lib.ffc_spectrum_bytes(plan.handle, 4, 8) == 0
+    plan = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
+    u = torch.zeros(2, 8, 512, device="cuda", dtype=torch.bfloat16); kf = torch.zeros(8, plan.kf_elems, 2, device="cuda", dtype=torch.bfloat16)
+    z = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), _lib.ptr(z), 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
+    assert rc != 0 and b"spectrum" in lib.ffc_last_error()
+    # small sizes and gated calls train through the recomputing path
+    conv = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()
+    uu = (torch.randn(2, 8, 512, device="cuda") * 0.1).bfloat16().requires_grad_(True); kk = torch.randn(8, 512, device="cuda").requires_grad_(True)
+    conv(uu, kk).sum().backward()
+    assert uu.grad is not None and kk.grad is not None
