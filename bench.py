@@ -3,7 +3,10 @@
 Step = one forward + backward of FlashFFTConv(32768) on BASELINE.json configs[1]
 (B=16, H=768, L=16384, bf16 activations, fp32 k), synthetic randn inputs resident in HBM:
    k -> k_f (kfft kernel), conv forward, fused backward (du + fp32 dk_f partial sums), dk inverse.
-Nothing is cached between steps (the reference recomputes k_f every forward, conv.py:572-575).
+Nothing is cached between steps (the reference recomputes k_f every forward, conv.py:572-575).  The module default is timed:
+its training forward keeps FFT(u) for the backward pass of the same step (module.save_spectrum, 2x the bytes of u), so the
+backward kernel runs two transforms per pair instead of three; the object `recompute` holds the same step with
+save_spectrum = False (the reference's memory footprint: its backward kernels transform u again).
 
 N > 1 GPUs: one process per GPU, heads sharded, no data-path collective.  `value` is the WEAK-scaled job (every rank runs
 the full per-GPU shape on its own heads: 768 heads per GPU); the object `strong` holds the FIXED problem of the BASELINE
@@ -22,6 +25,7 @@ for p in (os.path.join(ROOT, "flash-fft-conv_amd"), ROOT):
 import torch
 
 CFG = dict(N=32768, B=16, H=768, L=16384, dtype=torch.bfloat16)
+# nominal peaks (MI355X_MICROARCH.md); the measured ones of the box are reported as `peak_measured`
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16
 MFMA_FLOP = 2 * 32 * 32 * 16  # one v_mfma_f32_32x32x16_bf16
@@ -160,6 +164,10 @@ def main():
         mod(u, k).backward(dout)
 
     el = timed_steps(step, args.steps, args.warmup, dist, dev)
+    # the same step with the reference's memory footprint (FFT(u) recomputed by the backward kernel)
+    mod.save_spectrum = False
+    el_rc = timed_steps(step, args.steps, args.warmup, dist, dev)
+    mod.save_spectrum = True
 
     # ---- strong scaling: the FIXED B=16 x H=768 problem, this rank's H/world heads (no collective in the data path)
     strong = None
@@ -182,18 +190,50 @@ def main():
     ud, kd = u.detach(), k.detach()
     kf = C._kernel_fft(plan, kd)
     lib = _lib.lib()
+    P = _lib.ptr
     ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=dev)
+    zb = torch.empty(lib.ffc_spectrum_bytes(plan.handle, B, H), dtype=torch.uint8, device=dev)
     dk = torch.empty(H, L, dtype=torch.float32, device=dev)
     dk_du = torch.empty_like(ud)
+    y_buf = torch.empty_like(ud)
     sp = _lib.stream_ptr
-    kt = {
-        "kfft": time_kernel(lambda: C._kernel_fft(plan, kd)),
+    calls = {
+        "kfft": lambda: _lib.check(lib.ffc_kernel_fft(plan.handle, P(kd), H, L, P(kf), sp()), "kfft"),
+        "conv_fwd_save": lambda: _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(ud), P(kf), None, None, P(y_buf), P(zb), B, H, L, 0, 0, 0, 0, sp()), "fwd_z"),
+        "bwd_fused_saved": lambda: _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(ud), P(kf), None, None, P(dk_du), None, None, P(ws), P(zb), B, H, L,
+                                                             0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z"),
+        "dk_ifft": lambda: _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws), B, H, L, P(dk), sp()), "dk"),
+    }
+    # (a) inside the step sequence: one event after every launch of K back-to-back steps (what the step really pays per kernel:
+    #     a kernel that starts on the heels of another one runs slower than in a loop of its own)
+    order = ["kfft", "conv_fwd_save", "bwd_fused_saved", "dk_ifft"]
+    for _ in range(5):
+        for n in order: calls[n]()
+    torch.cuda.synchronize()
+    K = 20
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)] for _ in range(K)]
+    for i in range(K):
+        evs[i][0].record()
+        for j, n in enumerate(order):
+            calls[n](); evs[i][j + 1].record()
+    torch.cuda.synchronize()
+    kt_step = {n: sum(evs[i][j].elapsed_time(evs[i][j + 1]) for i in range(K)) / K * 1e-3 for j, n in enumerate(order)}
+    # (b) each kernel in a loop of its own, plus the recomputing pair and the two halves of the backward for reference
+    kt = {n: time_kernel(calls[n]) for n in order}
+    kt.update({
         "conv_fwd": time_kernel(lambda: C._conv(plan, ud, kf, None, None, False)),
         "conv_dx": time_kernel(lambda: C._conv(plan, dout, kf, None, None, True)),
-        "bwd_fused": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(dout), _lib.ptr(ud), _lib.ptr(kf), None, None, _lib.ptr(dk_du), None, _lib.ptr(ws), B, H, L, sp()), "bwd")),
-        "dkf_only": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(dout), _lib.ptr(ud), None, None, _lib.ptr(ws), B, H, L, sp()), "dkf")),
-        "dk_ifft": time_kernel(lambda: _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, _lib.ptr(ws), B, H, L, _lib.ptr(dk), sp()), "dk")),
-    }
+        "bwd_fused": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd(plan.handle, P(dout), P(ud), P(kf), None, None, P(dk_du), None, P(ws), B, H, L, sp()), "bwd")),
+        "dkf_only": time_kernel(lambda: _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, P(dout), P(ud), None, None, P(ws), B, H, L, sp()), "dkf")),
+    })
+    peaks = None
+    if rank == 0:
+        import ctypes
+        cg, mt = ctypes.c_double(), ctypes.c_double()
+        del zb
+        if lib.ffc_debug_peaks(ctypes.byref(cg), ctypes.byref(mt)) == 0:
+            peaks = {"stream_copy_GBs": round(cg.value), "mfma_bf16_dense_TFLOPs": round(mt.value),
+                     "how": "16 B per lane copy of 1 GiB (read + write bytes); register-resident v_mfma_f32_32x32x16_bf16 loop; best of 5 / 3"}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -246,10 +286,18 @@ def main():
              "basis": "achieved = algorithmic bytes (or executed MFMA flops) per launch / HIP-event launch time of this run"}
         return r
 
-    roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> (fused backward: du + fp32 dk_f)", mf_bwd, dense_bwd, bwd_bytes,
-                    kt["bwd_fused"], prof_traffic("r02_pmc_bwd_kernel.txt", "traffic"))
-    roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF> (forward)", mf_fwd, dense_fwd, fwd_bytes, kt["conv_fwd"],
-                    prof_traffic("r02_pmc_conv_kernel.txt", "traffic"))
+    # the backward kernel on saved spectra executes one forward half + one inverse half per pair
+    mf_bwd_saved = mf_bwd - 32 * (4 + 16)
+    roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> on saved spectra (fused backward: du + fp32 dk_f)", mf_bwd_saved, dense_bwd, bwd_bytes,
+                    kt_step["bwd_fused_saved"], prof_traffic("r03_pmc_bwd_kernel.txt", "traffic"))
+    roof_bwd["launch_ms_isolated_loop"] = kt["bwd_fused_saved"] * 1e3
+    roof_bwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_read": npair * N * 4}
+    roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> (training forward, stores the spectra)", mf_fwd, dense_fwd, fwd_bytes,
+                    kt_step["conv_fwd_save"], prof_traffic("r03_pmc_conv_kernel.txt", "traffic"))
+    roof_fwd["launch_ms_isolated_loop"] = kt["conv_fwd_save"] * 1e3
+    roof_fwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_write": npair * N * 4}
+    roof_bwd_rc = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> recomputing FFT(u) (save_spectrum = False)", mf_bwd, dense_bwd, bwd_bytes,
+                       kt["bwd_fused"], prof_traffic("r02_pmc_bwd_kernel.txt", "traffic"))
     out = {
         "metric": "FFT-conv fwd+bwd seq/s, B=16 H=768 L=16384 fft=32768 bf16",
         "value": seq_s, "unit": "seq/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -259,22 +307,32 @@ def main():
                    "per_gpu_rows": rows, "parallelism": f"head-shard x{world} (no collective)"},
         "tflops_dense_monarch": world * rows * dense_fwd * 2.5 / sec_per_step / 1e12,
         "tflops_fft_equiv": world * rows * (fft_fwd + fft_bwd) / sec_per_step / 1e12,
-        "kernel_ms": {n: v * 1e3 for n, v in kt.items()},
+        "kernel_ms": {n: v * 1e3 for n, v in kt_step.items()},
+        "kernel_ms_how": "HIP events between the launches of 20 back-to-back steps (k -> k_f, forward, fused backward, dk inverse)",
+        "kernel_ms_isolated_loops": {n: v * 1e3 for n, v in kt.items()},
         "roofline": roof_bwd,
         "roofline_fwd": roof_fwd,
+        "roofline_bwd_recompute": roof_bwd_rc,
+        "recompute": {"value": world * rows / (el_rc / args.steps), "unit": "seq/s", "ms_per_step": el_rc / args.steps * 1e3,
+                      "what": "the same step with module.save_spectrum = False: the backward kernel transforms u again (reference behaviour, "
+                              "no spectra kept between forward and backward)"},
+        "saved_for_backward_bytes": {"u": B * H * L * 2, "k_f": H * N * 4, "spectra (save_spectrum)": npair * N * 4},
+        "peak_measured": peaks,
     }
     if strong is not None:
         out["strong"] = strong
     if world == 1 and not args.no_sweep:
         # the rest of the BASELINE metric, timed in this same process with HIP events (benchmarks/sweep.py): the other
         # configs and the L = 1K .. 1M sweep at B=16 H=768 (fwd / bwd ms at module level, incl. k -> k_f and dk)
-        del u, k, dout, ud, kd, kf, ws, dk, dk_du
+        del u, k, dout, ud, kd, kf, ws, dk, dk_du, y_buf
         torch.cuda.empty_cache()
         from benchmarks import sweep as SW
-        keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
+        keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "fwd_ms_min", "bwd_ms_min", "fwd_infer_ms", "timing", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
                 "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac")
         out["configs"] = [{kk: r[kk] for kk in keep if kk in r} for r in list(SW.config_rows())[1:]]
         out["sweep"] = [{kk: r[kk] for kk in keep if kk in r} for r in SW.sweep_rows()]
+        # the reference's published table (gated forward, fp16, L = N, scaled to B=64 x H=768; 1 x H100-SXM, README.md:224-230)
+        out["readme_table"] = list(SW.readme_rows())
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out), flush=True)

@@ -10,16 +10,28 @@ import torch
 from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d
 
 
-def ev_time(fn, iters):
+REPEATS = 3
+
+
+def ev_time(fn, iters, repeats=REPEATS):
+    """HIP events around `iters` back-to-back calls, `repeats` times after 5 warm-up calls: (median, min) ms per call."""
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    ts = []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def set_iters(N):
+    return 20 if N < 1048576 else 8 if N == 1048576 else 5
 
 
 def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
@@ -30,10 +42,13 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
     g = [torch.randn(B, Hrun, L, device=dev).to(dtype).requires_grad_(True) for _ in range(2)] if gated else []
     dout = torch.randn(B, Hrun, L, device=dev).to(dtype)
     mod = FlashFFTConv(N, dtype=dtype).to(dev)
-    iters = 20 if N <= 4096 else 10 if N <= 1048576 else 5
+    iters = set_iters(N)
+    # forward = the TRAINING forward (grad enabled: it also stores what the backward pass reads, e.g. the spectra of
+    # module.save_spectrum); the inference forward (no_grad, eval) is reported next to it
+    (t_f, t_f_min) = ev_time(lambda: mod(u, k, *g), iters)
     with torch.no_grad():
         mod.eval()
-        t_f = ev_time(lambda: mod(u, k, *g), iters)
+        (t_fi, _) = ev_time(lambda: mod(u, k, *g), iters)
         mod.train()
     y = mod(u, k, *g)
     leaves = [u, k] + g
@@ -42,9 +57,9 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
         for t in leaves:
             t.grad = None          # otherwise autograd adds an accumulate pass over every gradient tensor
         y.backward(dout, retain_graph=True)
-    t_b = ev_time(bwd, iters)
+    (t_b, t_b_min) = ev_time(bwd, iters)
     scale = H / Hrun
-    t_f, t_b = t_f * scale, t_b * scale
+    t_f, t_b, t_fi, t_f_min, t_b_min = t_f * scale, t_b * scale, t_fi * scale, t_f_min * scale, t_b_min * scale
     rows = B * H
     lg = math.log2(N)
     fft_f, fft_b = 2 * 5 * N * lg + 6 * N, 3 * 5 * N * lg + 14 * N
@@ -53,6 +68,8 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
     return ({"row": name, "fft": N, "B": B, "H": H, "L": L, "dtype": str(dtype).split(".")[-1], "gated": gated,
                       "H_run": Hrun, "rescaled": Hrun != H,
                       "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4), "fwd_bwd_ms": round(t_f + t_b, 4),
+                      "fwd_ms_min": round(t_f_min, 4), "bwd_ms_min": round(t_b_min, 4), "fwd_infer_ms": round(t_fi, 4),
+                      "timing": f"median (and min) of {REPEATS} x {iters} iterations, HIP events",
                       "seq_per_s": round(rows / ((t_f + t_b) * 1e-3)),
                       "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
                       "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9),
@@ -66,7 +83,7 @@ def conv1d_row():
     m = FlashDepthWiseConv1d(D, K, 1, ref.weight.detach(), ref.bias.detach(), is_bhl=True, device="cuda", dtype=torch.bfloat16)
     x = torch.randn(B, D, L, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     with torch.no_grad():
-        t_f = ev_time(lambda: m(x), 10)
+        (t_f, _) = ev_time(lambda: m(x), 20)
     y = m(x)
     dout = torch.randn_like(y)
     def bwd():
@@ -74,7 +91,7 @@ def conv1d_row():
         for prm in m.parameters():
             prm.grad = None
         y.backward(dout, retain_graph=True)
-    t_b = ev_time(bwd, 5)
+    (t_b, _) = ev_time(bwd, 20)
     byts = B * L * D * 2 * 2 + K * D * 2
     return ({"row": "cfg5 conv1d k=3 B=64 H=2048 L=8192 bf16 BHL", "fwd_ms": round(t_f, 4), "bwd_ms": round(t_b, 4),
                       "fwd_GBs": round(byts / (t_f * 1e-3) / 1e9), "bwd_GBs": round(1.5 * byts / (t_b * 1e-3) / 1e9),
@@ -99,6 +116,37 @@ def sweep_rows(lg_lo=10, lg_hi=20):
         torch.cuda.empty_cache()
 
 
+# The reference's published table (README.md:224-230): gated forward, fp16, L = N, time scaled to
+# B = 64 x H = 768 rows, 1 x H100-SXM.  Same shapes here (B, H shrunk as the reference's set_B_H does and rescaled the same
+# way, benchmarks/benchmark_flashfftconv.py:28-59, :111), same training-mode forward.
+H100_GATED_FWD_MS = {256: 0.11, 1024: 0.29, 4096: 1.43, 8192: 3.58, 16384: 12.2, 32768: 26.3, 1048576: 1768.9, 2097152: 4623.5,
+                     4194304: 10049.4}
+
+
+def _ref_B_H(seqlen, B=64, H=768):
+    if seqlen == 16384: B = min(B, 32)
+    if seqlen == 32768: B = min(B, 16)
+    if seqlen >= 65536: B = min(B, 8)
+    cap = {131072: 384, 262144: 192, 524288: 96, 1048576: 48, 2097152: 32, 4194304: 16}
+    return B, min(H, cap.get(seqlen, H))
+
+
+def readme_rows(sizes=None):
+    for N in (sizes or sorted(H100_GATED_FWD_MS)):
+        B, H = _ref_B_H(N)
+        u = torch.randn(B, H, N, device="cuda").to(torch.float16).requires_grad_(True)
+        k = torch.randn(H, N, device="cuda").requires_grad_(True)
+        g = [torch.randn(B, H, N, device="cuda").to(torch.float16).requires_grad_(True) for _ in range(2)]
+        mod = FlashFFTConv(N, dtype=torch.float16).cuda()
+        (t, tmin) = ev_time(lambda: mod(u, k, *g), set_iters(N))
+        adj = 64 * 768 / (B * H)
+        yield {"row": f"README table N={N}", "fft": N, "L": N, "dtype": "float16", "gated": True, "B_run": B, "H_run": H,
+               "fwd_ms_scaled_to_B64_H768": round(t * adj, 3), "fwd_ms_min_scaled": round(tmin * adj, 3),
+               "h100_ms_published": H100_GATED_FWD_MS[N], "speedup_vs_h100_published": round(H100_GATED_FWD_MS[N] / (t * adj), 2)}
+        del u, k, g
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "configs"):
@@ -106,4 +154,7 @@ if __name__ == "__main__":
             print(json.dumps(r), flush=True)
     if which in ("all", "sweep"):
         for r in sweep_rows():
+            print(json.dumps(r), flush=True)
+    if which in ("all", "readme"):
+        for r in readme_rows():
             print(json.dumps(r), flush=True)

@@ -57,9 +57,68 @@ __global__ __launch_bounds__(256) void poison_kernel(uint32_t pat, int words, ui
   __builtin_amdgcn_s_sleep(64);
 }
 
+// Measured peaks of the box the process runs on (bench.py `peak_measured`; SURVEY.md section 6 asks for them next to the
+// nominal 8 TB/s / 2.5 PFLOP/s): a 16-byte-per-lane stream copy and a register-resident v_mfma_f32_32x32x16_bf16 loop.
+__global__ void peak_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void peak_mfma_kernel(float* sink, int iters) {
+  const int lane = threadIdx.x & 63;
+  DevB::A16 acc[4];
+  for (int j = 0; j < 4; j++) acc[j] = DevB::a16_zero();
+  DevB::W4 a = DevB::w4(0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u), b = DevB::w4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u + lane, 0x3c003c00u);
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) DevB::mfma<DT_BF16>(acc[j], a, b);
+  }
+  float s = 0.f;
+  for (int j = 0; j < 4; j++) for (int i = 0; i < 16; i++) s += acc[j][i];
+  if (s == 12345.678f) sink[0] = s;
+}
+
 extern "C" {
 
 void ffc_set_error_(const char* m) { g_err = m; }
+int ffc_debug_peaks(double* copy_GBs, double* mfma_TFLOPs) {
+  if (!copy_GBs || !mfma_TFLOPs) return fail("null arg");
+  int dev = 0, ncu = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+  const size_t bytes = (size_t)1 << 30;
+  uint4 *s = nullptr, *d = nullptr; float* sink = nullptr;
+  hipEvent_t e0, e1;
+  if (hipMalloc((void**)&s, bytes) != hipSuccess || hipMalloc((void**)&d, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess ||
+      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    if (s) (void)hipFree(s);
+    if (d) (void)hipFree(d);
+    return fail("peak probe: allocation failed");
+  }
+  (void)hipMemset(s, 1, bytes); (void)hipMemset(d, 2, bytes);
+  double bc = 0, bm = 0;
+  for (int rep = 0; rep < 6; rep++) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(ncu * 8), dim3(512), 0, 0, s, d, bytes / 16);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms > 0 && 2.0 * bytes / (ms * 1e-3) / 1e9 > bc) bc = 2.0 * bytes / (ms * 1e-3) / 1e9;
+  }
+  const int iters = 20000;
+  for (int rep = 0; rep < 4; rep++) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(peak_mfma_kernel, dim3(ncu * 4), dim3(256), 0, 0, sink, iters);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    double fl = (double)ncu * 4 * 4 * iters * 4 * (2.0 * 32 * 32 * 16);
+    if (rep && ms > 0 && fl / (ms * 1e-3) / 1e12 > bm) bm = fl / (ms * 1e-3) / 1e12;
+  }
+  (void)hipFree(s); (void)hipFree(d); (void)hipFree(sink);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *copy_GBs = bc; *mfma_TFLOPs = bm;
+  return 0;
+}
 int ffc_version(void) { return 100; }
 const char* ffc_last_error(void) { return g_err.c_str(); }
 

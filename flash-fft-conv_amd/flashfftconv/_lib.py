@@ -48,6 +48,7 @@ def lib():
         L.ffc_conv1d_fwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]
         L.ffc_conv1d_bwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]
         L.ffc_debug_poison.argtypes = [c_vp]
+        L.ffc_debug_peaks.argtypes = [c_vp, c_vp]
         L.ffc_selftest_primitives.argtypes = [c_vp, c_vp]
         L.ffc_conv_fwd_prof.argtypes = [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]
         _lib = L

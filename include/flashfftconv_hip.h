@@ -136,6 +136,8 @@ int ffc_conv_fwd_prof(const ffc_plan* plan, const void* u, const void* kf, void*
 /* Test support: fills every CU's LDS and vector/accumulation registers with NaN patterns (a kernel that reads
  * state it never initialised then fails loudly instead of inheriting the previous workgroup's benign leftovers). */
 int ffc_debug_poison(void* stream);
+/* measured peaks of the current device: stream copy (GB/s, read + write bytes) and dense v_mfma_f32_32x32x16_bf16 (TFLOP/s) */
+int ffc_debug_peaks(double* copy_GBs, double* mfma_TFLOPs);
 
 /* Hardware-primitive self test (MFMA lane layouts, ds_read_b64_tr_b16, packing): fills `out_host`
  * (host memory, 64*40 uint32) for comparison against the CPU wave simulator.  Test support. */
