@@ -199,7 +199,7 @@ def main():
     sp = _lib.stream_ptr
     calls = {
         "kfft": lambda: _lib.check(lib.ffc_kernel_fft(plan.handle, P(kd), H, L, P(kf), sp()), "kfft"),
-        "conv_fwd_save": lambda: _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(ud), P(kf), None, None, P(y_buf), P(zb), B, H, L, 0, 0, 0, 0, sp()), "fwd_z"),
+        "conv_fwd_save": lambda: _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(ud), P(kf), None, None, P(y_buf), P(zb), None, B, H, L, 0, 0, 0, 0, sp()), "fwd_z"),
         "bwd_fused_saved": lambda: _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(ud), P(kf), None, None, P(dk_du), None, None, P(ws), P(zb), B, H, L,
                                                              0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z"),
         "dk_ifft": lambda: _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws), B, H, L, P(dk), sp()), "dk"),

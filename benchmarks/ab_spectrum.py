@@ -24,12 +24,15 @@ for (N, B, H, L, gated) in cases:
     ws2 = torch.empty_like(ws)
     z = torch.empty(lib.ffc_spectrum_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda")
     y0, y1 = torch.empty_like(u), torch.empty_like(u)
+    yraw = torch.empty_like(u) if gated else None
     outs0 = [torch.empty_like(u) for _ in range(3)]; outs1 = [torch.empty_like(u) for _ in range(3)]
     g = lambda t: P(t) if gated else None
     f0 = lambda: _lib.check(lib.ffc_conv_fwd(plan.handle, P(u), P(kf), P(pre), P(post), P(y0), B, H, L, 0, sp()), "fwd")
-    f1 = lambda: _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y1), P(z), B, H, L, 0, 0, 0, 0, sp()), "fwd_z")
+    f1 = lambda: _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y1), P(z), P(yraw), B, H, L, 0, 0, 0, 0, sp()), "fwd_z")
     b0 = lambda: _lib.check(lib.ffc_conv_bwd_gated(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(outs0[0]), g(outs0[1]), g(outs0[2]), P(ws), B, H, L, sp()), "bwd")
-    b1 = lambda: _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(outs1[0]), g(outs1[1]), g(outs1[2]), P(ws2), P(z), B, H, L, 0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
+    def b1():
+        if gated: torch.mul(dout, yraw, out=outs1[2])      # dpostgate from the saved pre-postgate output
+        _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(outs1[0]), g(outs1[1]), None, P(ws2), P(z), B, H, L, 0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
     f0(); f1(); b0(); b1(); torch.cuda.synchronize()
     dk0 = torch.empty(H, L, device="cuda"); dk1 = torch.empty(H, L, device="cuda")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws), B, H, L, P(dk0), sp()), "dk")

@@ -56,6 +56,9 @@ struct ConvArgs {
   // (head, pair): [H][npair][N][2]) is stored here for the backward pass, which then skips its first transform
   // (ffc_conv_fwd_z / ffc_conv_bwd_z).  Fused single-pass sizes with an outer digit (fft 4096 ... 32768) only.
   void* zsave;
+  // with zsave, optional: the output BEFORE the postgate multiply, contiguous (B,H,L) dtype (the gated backward's
+  // dpostgate = dout * this, which then needs no inverse transform of the saved spectrum)
+  void* yraw;
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -1388,6 +1391,13 @@ struct Body {
         outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
         B::lds_fence();
         FFC_TICK(5)
+        if constexpr (SZ) {
+          if (a.yraw) {
+            ConvArgs ar = a;
+            ar.y = a.yraw; ar.postgate = nullptr; ar.sby = (int64_t)a.H * a.L;
+            rows_out<NC>(ar, h, p, un);
+          }
+        }
         if constexpr (RP) rows_out_rp<NC>(a, h, p, un, ps);
         else rows_out<NC>(a, h, p, un);
         FFC_TICK(6)

@@ -116,7 +116,7 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
   return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;
 }
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
-                         void* y, void* zsave, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                         void* y, void* zsave, void* yraw, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                          int64_t sb_post, int64_t sb_y, void* stream) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
@@ -131,7 +131,7 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_y;
   a.conj_kf = conj_kf;
-  a.zsave = zsave;
+  a.zsave = zsave; a.yraw = zsave ? yraw : nullptr;
   if (zsave && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zsave & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.flags = p->env_flags;
@@ -148,14 +148,16 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
 extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                                     void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                                     int64_t sb_post, int64_t sb_y, void* stream) {
-  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, B, H, L, conj_kf, sb_u, sb_pre, sb_post, sb_y, stream);
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, nullptr, B, H, L, conj_kf, sb_u, sb_pre, sb_post, sb_y, stream);
 }
-// forward that also stores every pair's spectrum FFT(u * pregate) in `zsave` (ffc_spectrum_bytes) for ffc_conv_bwd_z
+// forward that also stores every pair's spectrum FFT(u * pregate) in `zsave` (ffc_spectrum_bytes) for ffc_conv_bwd_z and,
+// when y_raw is given (16-byte aligned, contiguous (B,H,L)), the output before the postgate multiply
 extern "C" int ffc_conv_fwd_z(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
-                              void* zsave, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                              void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                               int64_t sb_y, void* stream) {
   if (!zsave) return ffc_fail("null spectrum buffer");
-  return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
+  if (y_raw && ((uintptr_t)y_raw & 15)) return ffc_fail("y_raw must be 16-byte aligned");
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, y_raw, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
 }
 
 extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,

@@ -113,11 +113,11 @@ def _spectrum_buffer(plan, B, H, device):
         return None
 
 
-def _conv_save(plan, u, kf, pregate, postgate, z):
+def _conv_save(plan, u, kf, pregate, postgate, z, yraw=None):
     B, H, L = u.shape
     y = torch.empty_like(u)
     _lib.check(_lib.lib().ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate), _lib.ptr(y),
-                                         _lib.ptr(z), B, H, L, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_fwd_z")
+                                         _lib.ptr(z), _lib.ptr(yraw), B, H, L, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_fwd_z")
     return y
 
 
@@ -271,23 +271,27 @@ class _FlashFFTConvFn(torch.autograd.Function):
                     kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
                 if mod.cache_kf and not k.requires_grad:
                     mod._kf_cache = (_kf_key(k), kf)
-            # MI355X design (memory laid out for 288 GB of HBM): an ungated training forward keeps every pair's spectrum
-            # FFT(u) (2x the bytes of u at L = N/2) so that the backward pass does not transform u a second time: its
+            # MI355X design (memory laid out for 288 GB of HBM): a training forward keeps every pair's spectrum
+            # FFT(u * pregate) (2x the bytes of u at L = N/2) so that the backward pass does not transform u a second time: its
             # kernel runs two transforms per pair instead of three (fused backward -30 % at B16 H768 fft 32768,
-            # profiles/r03_spectrum.txt).  module.save_spectrum = False (or FFC_SAVE_SPECTRUM=0) keeps the reference's
-            # recomputing backward.  Not for the gated form: its backward needs the first spectrum's inverse for dpostgate anyway
-            # and the extra forward store costs what the backward saves.
-            z = None
-            if mod.training and mod.save_spectrum and not ctx.gated and any(ctx.needs_input_grad[:2]):
+            # profiles/r03_spectrum.txt).  The gated form also keeps the output before the postgate multiply (1x the bytes
+            # of u): dpostgate = dout * that, instead of one more inverse transform of the spectrum.
+            # module.save_spectrum = False (or FFC_SAVE_SPECTRUM=0) keeps the reference's recomputing backward.
+            z = yraw = None
+            if mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
                 z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device)
-            out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z)
+                if z is not None and ctx.gated:
+                    try:
+                        yraw = torch.empty_like(u)
+                    except torch.cuda.OutOfMemoryError:
+                        z = None
+            out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
+            # (z, yraw: saved tensors, released with the graph and kept by retain_graph like the others)
             if ctx.gated:
-                ctx.save_for_backward(u, kf, pregate, postgate)
-            elif not ctx.big and z is not None:
-                ctx.save_for_backward(u, kf, z)      # (a saved tensor: released with the graph, kept by retain_graph)
+                ctx.save_for_backward(*((u, kf, pregate, postgate) + (() if ctx.big or z is None else (z, yraw))))
             else:
-                ctx.save_for_backward(u, kf)
+                ctx.save_for_backward(*((u, kf) + (() if ctx.big or z is None else (z,))))
         return out
 
     @staticmethod
@@ -300,9 +304,11 @@ class _FlashFFTConvFn(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, dout):
         dout = dout.contiguous()
-        z = None
+        z = yraw = None
         if ctx.gated:
-            u, kf, pregate, postgate = ctx.saved_tensors
+            u, kf, pregate, postgate = ctx.saved_tensors[:4]
+            if len(ctx.saved_tensors) > 4:
+                z, yraw = ctx.saved_tensors[4:6]
         else:
             (u, kf), pregate, postgate = ctx.saved_tensors[:2], None, None
             z = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
@@ -317,10 +323,12 @@ class _FlashFFTConvFn(torch.autograd.Function):
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
-        dpost = torch.empty_like(u) if ctx.gated else None
+        dpost = torch.empty_like(u) if ctx.gated and z is None else None
         if z is not None:
+            if ctx.gated:
+                dpost = dout * yraw      # same product and rounding as the kernel's output gate (fp32 product of the two, rounded once)
             _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
-                                          _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws), _lib.ptr(z),
+                                          _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), None, _lib.ptr(ws), _lib.ptr(z),
                                           B, H, L, 0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
         else:
             _lib.check(lib.ffc_conv_bwd_gated(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),

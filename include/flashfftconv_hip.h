@@ -87,11 +87,13 @@ int ffc_conv_bwd_gated_strided(const ffc_plan* plan, const void* dout, const voi
  * ffc_conv_bwd_z reads it instead of transforming u again: one of the backward's three transforms per pair, its rows of u
  * and its scratch round trip disappear.  du / dpregate come out bit for bit as from ffc_conv_bwd_gated_strided; dk and dpostgate
  * agree to the rounding of the spectrum (the forward and the backward kernel schedule the same fp32 operations differently).  Fused single-pass sizes with an outer digit only (fft 4096 ... 32768):
- * ffc_spectrum_bytes() returns 0 for every other plan. */
+ * ffc_spectrum_bytes() returns 0 for every other plan.
+ * y_raw (nullable; contiguous (B,H,L) dtype): the forward output before the postgate multiply.  The gated backward's
+ * dpostgate is dout * y_raw -- with it the caller passes dpost = NULL to ffc_conv_bwd_z and that kernel runs no third transform. */
 int64_t ffc_spectrum_bytes(const ffc_plan* plan, int64_t B, int64_t H);
 int ffc_conv_fwd_z(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
-                   void* zsave, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_y,
-                   void* stream);
+                   void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                   int64_t sb_y, void* stream);
 int ffc_conv_bwd_z(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
                    const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
                    int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_du, int64_t sb_dpre,

@@ -27,13 +27,22 @@ def _call_pair(N, B, H, L, dtype, gated):
     z = torch.empty(zb, dtype=torch.uint8, device="cuda")
     ws0 = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda"); ws1 = torch.empty_like(ws0)
     y0, y1 = torch.full_like(u, 7.0), torch.full_like(u, 9.0)
+    yraw = torch.full_like(u, 11.0) if gated else None
     o0 = [torch.full_like(u, 3.0) for _ in range(3)]; o1 = [torch.full_like(u, 5.0) for _ in range(3)]
     g = (lambda t: P(t)) if gated else (lambda t: None)
     _lib.check(lib.ffc_conv_fwd(plan.handle, P(u), P(kf), P(pre), P(post), P(y0), B, H, L, 0, sp()), "fwd")
-    _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y1), P(z), B, H, L, 0, 0, 0, 0, sp()), "fwd_z")
+    _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y1), P(z), P(yraw), B, H, L, 0, 0, 0, 0, sp()), "fwd_z")
     _lib.check(lib.ffc_conv_bwd_gated(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o0[0]), g(o0[1]), g(o0[2]), P(ws0), B, H, L, sp()), "bwd")
-    _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o1[0]), g(o1[1]), g(o1[2]), P(ws1), P(z), B, H, L,
+    # saved spectra + saved pre-postgate output: dpostgate = dout * y_raw, no dpost from the kernel
+    _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o1[0]), g(o1[1]), None, P(ws1), P(z), B, H, L,
                                   0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
+    if gated:
+        o1[2] = dout * yraw
+        # the kernel can still produce dpost from the saved spectrum alone (one more inverse transform)
+        o2 = torch.full_like(u, 13.0)
+        _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o1[0]), g(o1[1]), P(o2), P(ws1), P(z), B, H, L,
+                                      0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
+        assert rel(o2, o0[2]) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
     dk0 = torch.empty(H, L, device="cuda"); dk1 = torch.empty(H, L, device="cuda")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws0), B, H, L, P(dk0), sp()), "dk")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws1), B, H, L, P(dk1), sp()), "dk")
@@ -61,32 +70,38 @@ def test_saved_spectrum_equals_recompute(N, gated, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gated", [False, True])
 @pytest.mark.parametrize("N", SIZES)
-def test_module_gradients_with_saved_spectrum(N, dtype):
+def test_module_gradients_with_saved_spectrum(N, gated, dtype):
     """module level: save_spectrum on (default) against the torch.fft oracle and against save_spectrum off."""
     from flashfftconv import FlashFFTConv
     torch.manual_seed(1)
     B, H, L = 6, 24, N // 2
     u, k = make_inputs(B, H, L, N, dtype, False)
+    gates = [torch.randn_like(u) * 0.5 for _ in range(2)] if gated else []
     dout = torch.randn_like(u) * 0.02
     grads = {}
     for save in (True, False):
         conv = FlashFFTConv(N, dtype=dtype).cuda()
         conv.save_spectrum = save
-        uu, kk = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
-        out = conv(uu, kk)
-        g = torch.autograd.grad(out, (uu, kk), dout, retain_graph=True)
-        g2 = torch.autograd.grad(out, (uu, kk), dout)
+        leaves = [u.clone().requires_grad_(True), k.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in gates]
+        out = conv(*leaves)
+        g = torch.autograd.grad(out, leaves, dout, retain_graph=True)
+        g2 = torch.autograd.grad(out, leaves, dout)
         assert all(torch.equal(a, b) for a, b in zip(g, g2)), "second backward through a retained graph differs"
         grads[save] = (out.detach(), g)
     assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1][0], grads[False][1][0])
-    uc, kc = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
-    (ref,) = stable(lambda: (ref_fft_conv(uc, kc, n=N),), "forward")
-    gref = stable(lambda: torch.autograd.grad(ref, (uc, kc), dout.clone(), retain_graph=True), "backward")
-    out, g = grads[True]
-    assert rel(out, ref) < REL[dtype] and rel(g[0], gref[0]) < REL[dtype]
-    assert rel(g[1], gref[1]) < max(REL[dtype], 1e-2), f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
-    assert rel(grads[False][1][1], gref[1]) < max(REL[dtype], 1e-2)
+    lc = [u.clone().requires_grad_(True), k.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in gates]
+    fwd = (lambda: (ref_fft_conv(lc[0] * lc[2], lc[1], n=N) * lc[3],)) if gated else (lambda: (ref_fft_conv(lc[0], lc[1], n=N),))
+    (ref,) = stable(fwd, "forward")
+    gref = stable(lambda: torch.autograd.grad(ref, lc, dout.clone(), retain_graph=True), "backward")
+    tol = REL[dtype] * (1.5 if gated else 1.0)
+    for save in (True, False):
+        out, g = grads[save]
+        assert rel(out, ref) < tol and rel(g[0], gref[0]) < tol
+        assert rel(g[1], gref[1]) < max(tol, 1e-2 * (1.5 if gated else 1.0)), f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
+        if gated:
+            assert rel(g[2], gref[2]) < tol and rel(g[3], gref[3]) < tol, f"gate gradients (save_spectrum={save})"
 
 
 def test_no_spectrum_path_for_other_plans():
@@ -98,7 +113,7 @@ def test_no_spectrum_path_for_other_plans():
     plan = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
     u = torch.zeros(2, 8, 512, device="cuda", dtype=torch.bfloat16); kf = torch.zeros(8, plan.kf_elems, 2, device="cuda", dtype=torch.bfloat16)
     z = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
-    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), _lib.ptr(z), 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
+    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), _lib.ptr(z), None, 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
     assert rc != 0 and b"spectrum" in lib.ffc_last_error()
     # small sizes and gated calls train through the recomputing path
     conv = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()
