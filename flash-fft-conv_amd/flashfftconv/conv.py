@@ -178,6 +178,27 @@ class _TorchOps:
                                         _lib.stream_ptr()), "ffc_conv_bwd_dkf")
         return ws
 
+    def conv_save(self, dt, M, x, kf):
+        """inner forward that also keeps the inner spectra (None when the inner plan has no such path)"""
+        plan = self._plan(M)
+        z = _spectrum_buffer(plan, x.shape[0], x.shape[1], self.device)
+        return (_conv(plan, x, kf, None, None, False), None) if z is None else (_conv_save(plan, x, kf, None, None, z), z)
+
+    def bwd(self, dt, M, xd, xu, kf, z=None):
+        """fused inner backward on pair-plane rows: (input gradient rows, fp32 dk_f slabs); z = spectra kept by conv_save"""
+        plan = self._plan(M)
+        Bp, hp, _ = xu.shape
+        lib = _lib.lib()
+        ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, Bp, hp), dtype=torch.uint8, device=self.device)
+        yd = torch.empty_like(xd)
+        if z is not None:
+            _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(xd), _lib.ptr(xu), _lib.ptr(kf), None, None, _lib.ptr(yd), None, None,
+                                          _lib.ptr(ws), _lib.ptr(z), Bp, hp, M, 0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
+        else:
+            _lib.check(lib.ffc_conv_bwd(plan.handle, _lib.ptr(xd), _lib.ptr(xu), _lib.ptr(kf), None, None, _lib.ptr(yd), None, _lib.ptr(ws),
+                                        Bp, hp, M, _lib.stream_ptr()), "ffc_conv_bwd")
+        return yd, ws
+
     def dkifft_c(self, M, ws, Bp, hp, scale):
         plan = self._plan(M)
         out = torch.empty(2, hp, M, dtype=torch.bfloat16, device=self.device)
@@ -186,29 +207,37 @@ class _TorchOps:
         return out
 
 
-def _big_forward(mod, u, k, pregate, postgate):
+def _big_forward(mod, u, k, pregate, postgate, keep=False):
+    """keep (training, module.save_spectrum): also return what the backward pass would otherwise compute again -- the
+    transformed input x of the inner size (pair-plane rows), the inner spectra z (inner plans with that path) and, for the
+    gated form, the inner output y (dpostgate = its inverse levels * dout)."""
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = _big.BIG_FACTORS[N][1]
     kf = _big.kernel_fft(ops, dt, N, k.detach().to(torch.float32).contiguous(), H, k.shape[-1])
     x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
-    y = ops.conv(dt, M, x, kf, False)
+    z = None
+    if keep:
+        y, z = ops.conv_save(dt, M, x, kf)
+    else:
+        y = ops.conv(dt, M, x, kf, False)
     out = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate)
-    return out, kf
+    return out, kf, ((x, z, y if pregate is not None else None) if keep else None)
 
 
-def _big_backward(mod, dout, u, kf, pregate, postgate, k_len):
+def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None):
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = _big.BIG_FACTORS[N][1]
     xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate)
-    xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
-    ws = ops.dkf(dt, M, xd, xu)
+    xu, z, yu = kept if kept is not None else (_big.levels_forward(ops, dt, N, u, B, H, L, pregate), None, None)
+    # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
+    # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
+    yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
     dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
-    yd = ops.conv(dt, M, xd, kf, True)
     du = torch.empty_like(u)
     shared = {}
     _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared)
@@ -216,7 +245,8 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len):
         return du, dk, None, None
     dpre = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared)
-    yu = ops.conv(dt, M, xu, kf, False)
+    if yu is None:
+        yu = ops.conv(dt, M, xu, kf, False)
     dpost = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout)
     return du, dk, dpre, dpost
@@ -260,8 +290,15 @@ class _FlashFFTConvFn(torch.autograd.Function):
         postgate = None if postgate is None else postgate.contiguous()
         ctx.mod, ctx.k_len, ctx.k_dtype, ctx.gated = mod, k.shape[-1], k.dtype, pregate is not None
         ctx.big = mod._big
+        kept = None
         if ctx.big:
-            out, kf = _big_forward(mod, u, k, pregate, postgate)
+            keep = mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+            try:
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, keep)
+            except torch.cuda.OutOfMemoryError:
+                if not keep:
+                    raise
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False)
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
             kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None
@@ -288,10 +325,12 @@ class _FlashFFTConvFn(torch.autograd.Function):
             out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             # (z, yraw: saved tensors, released with the graph and kept by retain_graph like the others)
-            if ctx.gated:
-                ctx.save_for_backward(*((u, kf, pregate, postgate) + (() if ctx.big or z is None else (z, yraw))))
+            if ctx.big:
+                extra = () if kept is None else tuple(t for t in kept if t is not None)
+                ctx.kept_layout = None if kept is None else tuple(t is not None for t in kept)
             else:
-                ctx.save_for_backward(*((u, kf) + (() if ctx.big or z is None else (z,))))
+                extra = () if z is None else ((z, yraw) if ctx.gated else (z,))
+            ctx.save_for_backward(*(((u, kf, pregate, postgate) if ctx.gated else (u, kf)) + extra))
         return out
 
     @staticmethod
@@ -313,7 +352,11 @@ class _FlashFFTConvFn(torch.autograd.Function):
             (u, kf), pregate, postgate = ctx.saved_tensors[:2], None, None
             z = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
         if ctx.big:
-            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len)
+            kept = None
+            if getattr(ctx, "kept_layout", None) is not None:
+                it = iter(ctx.saved_tensors[4 if ctx.gated else 2:])
+                kept = tuple(next(it) if present else None for present in ctx.kept_layout)
+            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len, kept)
             return du, dk.to(ctx.k_dtype), None, dpre, dpost
         plan = ctx.mod._get_plan(u.device, ctx.mod._plan_seqlen)
         B, H, L = u.shape
