@@ -1075,6 +1075,10 @@ struct Body {
   static FFC_FN uint8_t* z_slot(void* base, int h, int npair, int p) {
     return (uint8_t*)base + ((int64_t)h * npair + p) * ((int64_t)GEO::N * 4);
   }
+  // multi-pass sizes: [H][npair][R passes][M]
+  static FFC_FN uint8_t* z_slot_rp(void* base, int h, int npair, int p, int R, int k0) {
+    return (uint8_t*)base + (((int64_t)h * npair + p) * R + k0) * ((int64_t)GEO::N * 4);
+  }
   static FFC_FN void load_kf(const ConvArgs& a, int h, int tau, KfRegs& k) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
@@ -1370,7 +1374,8 @@ struct Body {
         if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2)
-            inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps, SZ ? z_slot(a.zsave, h, a.npair, p) : nullptr);
+            inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
+                                SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr);
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);
@@ -1395,7 +1400,8 @@ struct Body {
           if (a.yraw) {
             ConvArgs ar = a;
             ar.y = a.yraw; ar.postgate = nullptr; ar.sby = (int64_t)a.H * a.L;
-            rows_out<NC>(ar, h, p, un);
+            if constexpr (RP) rows_out_rp<NC>(ar, h, p, un, ps);
+            else rows_out<NC>(ar, h, p, un);
           }
         }
         if constexpr (RP) rows_out_rp<NC>(a, h, p, un, ps);

@@ -31,14 +31,14 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
 
 // multi-pass sizes (fft 65536 / 131072): the R passes of a (head, chunk) job run one after the other in the same workgroup,
 // so that the read-modify-write of the output rows stays inside one wave (struct Pass, Body::rows_out_rp)
-template <class GEO, int DT, bool HALF>
+template <class GEO, int DT, bool HALF, bool SZ = false>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_rp_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
   int h, chunk;
   if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
   BD::setup_tables(a.tab, a.t);
   if constexpr (!GEO::OUTER) BD::setup_tables_ipass(a.tab, a.t, a.R);     // inner-only form (fft 2048): per-pass tables
-  BD::template conv_job<HALF, true>(a, h, chunk);
+  BD::template conv_job<HALF, true, SZ>(a, h, chunk);
 }
 
 template <class GEO, int DT>
@@ -49,6 +49,19 @@ struct ConvLaunch {
     int grid = hpad * a.nchunk;
     if (a.R > 1) {
       if constexpr (GEO::N == 32768) {
+        if (a.zsave) {
+          if (16 * GEO::Mi >= a.L) {
+            static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, true, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+          } else {
+            static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
+            if (rc) return rc;
+            hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+          }
+          hipError_t e = hipGetLastError();
+          return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel (spectrum-saving) launch: ") + hipGetErrorString(e));
+        }
         if (16 * GEO::Mi >= a.L) {
           static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
@@ -112,8 +125,8 @@ static inline bool ffc_stride_ok(int64_t* sb, int64_t B, int64_t H, int64_t L) {
 
 // spectra saved for the backward pass: [H][npair][N] complex values of the plan dtype; 0 = this plan has no such path
 extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
-  if (!p || p->hp.N1 <= 1 || p->hp.R > 1 || B <= 0 || H <= 0) return 0;
-  return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;
+  if (!p || p->hp.N1 <= 1 || B <= 0 || H <= 0) return 0;
+  return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;        // (hp.N = the plan's fft size, R passes x the kernel size)
 }
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                          void* y, void* zsave, void* yraw, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,

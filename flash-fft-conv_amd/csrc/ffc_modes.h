@@ -808,7 +808,7 @@ struct Modes : Body<B, GEO, DT> {
       // before the last scratch store -- needs 32 live registers at points where the allocator, which treats a0..a127 as free
       // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
       // DESIGN.md section 7)
-      const bool have_z = !RP && d.zin != nullptr;
+      const bool have_z = d.zin != nullptr;
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -817,7 +817,9 @@ struct Modes : Body<B, GEO, DT> {
         if constexpr (!RP) pt0 = B::clock();
 #endif
         // saved spectra (d.zin): the pair's first transform is skipped, its spectrum is read from the forward pass's copy
-        const void* zp = have_z ? (const void*)BD::z_slot(const_cast<void*>(d.zin), h, a.npair, act ? p : p0) : (const void*)zs;
+        const void* zp = !have_z ? (const void*)zs
+                         : RP ? (const void*)BD::z_slot_rp(const_cast<void*>(d.zin), h, a.npair, act ? p : p0, a.R, k0)
+                              : (const void*)BD::z_slot(const_cast<void*>(d.zin), h, a.npair, act ? p : p0);
         if (have_z) {
           if (d.dpost) {
             // forward output of this pair for dpost: iFFT(Z_u * k_f) into E.  The previous pair's phase C read every E row.
@@ -840,12 +842,14 @@ struct Modes : Body<B, GEO, DT> {
             if (act) {
               BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
               B::lds_fence();
-              BD::template rows_out<NCX>(aq, h, p, un);
+              if constexpr (RP) BD::template rows_out_rp<NCX>(aq, h, p, un, ps);
+              else BD::template rows_out<NCX>(aq, h, p, un);
             }
           }
           FFC_BTICK(5)
           if (act) {
-            BD::template rows_in<NCX>(ad, h, p, un);
+            if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
+            else BD::template rows_in<NCX>(ad, h, p, un);
             B::lds_fence();
             FFC_BTICK(6)
             BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
