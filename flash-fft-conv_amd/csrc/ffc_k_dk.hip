@@ -67,3 +67,18 @@ extern "C" int ffc_kernel_ifft_grad_c(const ffc_plan* p, const void* ws, int64_t
   a.R = p->hp.R;
   return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
 }
+
+// the same from `nslab` caller-owned fp32 slabs [nslab][H][kf_elems][2] (B-shard of the big FFT sizes: rows reduce-scattered
+// over the ranks, flashfftconv/sharding.py)
+extern "C" int ffc_kernel_ifft_grad_c_slabs(const ffc_plan* p, const void* slabs, int64_t nslab, int64_t H, void* outpair, float scale,
+                                            void* stream) {
+  if (!p || !slabs || !outpair) return ffc_fail("null arg");
+  if (p->hp.N1 <= 1) return ffc_fail("ffc_kernel_ifft_grad_c_slabs: inner size must be >= 4096");
+  if (H <= 0 || nslab <= 0 || nslab > 65536) return ffc_fail("bad head / slab count");
+  if ((uintptr_t)slabs & 15) return ffc_fail("slabs must be 16-byte aligned");
+  DkArgs a{};
+  a.ws = (const float*)slabs; a.outpair = outpair; a.tab = p->d_blob_bf; a.t = p->hp_bf.tabs; a.H = (int)H; a.Lk = p->hp.N;
+  a.nslab = (int)nslab; a.scale = scale; a.s_inv = (float)p->hp_bf.s_inv; a.fast = 1;
+  a.R = p->hp.R;
+  return ffc_dispatch<DkLaunch>(p->hp.N, DT_BF16, a, (hipStream_t)stream);
+}

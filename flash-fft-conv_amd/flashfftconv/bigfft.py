@@ -100,14 +100,16 @@ def kernel_fft(ops, dt, N, k, H, Lk):
     return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N) * pre))
 
 
-def dk_from_slabs(ops, N, ws, Bp, H, Lk):
-    """fp32 W slabs of the inner size -> dk (H, Lk) fp32.  Always bf16 arithmetic (fp32 range)."""
+def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None):
+    """fp32 W slabs of the inner size -> dk (H, Lk) fp32.  Always bf16 arithmetic (fp32 range).
+    nslab: `ws` holds that many caller-owned slabs (hp, kf_elems, 2) instead of a backward launch's workspace."""
     factors, M = BIG_FACTORS[N]
     hp = H
     for n0 in factors:
         hp *= n0
     BF = ops.BF16
-    y = ops.dkifft_c(M, ws, Bp, hp, 1.0 / (inner_sfwd(M) * prod_scale(N)))     # (2, hp, M) bf16
+    sc = 1.0 / (inner_sfwd(M) * prod_scale(N))
+    y = ops.dkifft_c(M, ws, Bp, hp, sc) if nslab is None else ops.dkifft_c(M, ws, Bp, hp, sc, nslab)     # (2, hp, M) bf16
     out = ops.empty_pair(BF, 1, H, Lk)
     levels_inverse(ops, BF, N, y, out, 1, H, Lk)
     return ops.to_float_rows(out, H, Lk)

@@ -199,23 +199,35 @@ class _TorchOps:
                                         Bp, hp, M, _lib.stream_ptr()), "ffc_conv_bwd")
         return yd, ws
 
-    def dkifft_c(self, M, ws, Bp, hp, scale):
+    def dkifft_c(self, M, ws, Bp, hp, scale, nslab=None):
         plan = self._plan(M)
         out = torch.empty(2, hp, M, dtype=torch.bfloat16, device=self.device)
-        _lib.check(_lib.lib().ffc_kernel_ifft_grad_c(plan.handle, _lib.ptr(ws), Bp, hp, _lib.ptr(out), ctypes.c_float(scale),
-                                                     _lib.stream_ptr()), "ffc_kernel_ifft_grad_c")
+        if nslab is None:
+            _lib.check(_lib.lib().ffc_kernel_ifft_grad_c(plan.handle, _lib.ptr(ws), Bp, hp, _lib.ptr(out), ctypes.c_float(scale),
+                                                         _lib.stream_ptr()), "ffc_kernel_ifft_grad_c")
+        else:      # caller-owned slabs (B-shard: the reduce-scattered rows of this rank's heads)
+            _lib.check(_lib.lib().ffc_kernel_ifft_grad_c_slabs(plan.handle, _lib.ptr(ws), nslab, hp, _lib.ptr(out), ctypes.c_float(scale),
+                                                               _lib.stream_ptr()), "ffc_kernel_ifft_grad_c_slabs")
         return out
 
 
-def _big_forward(mod, u, k, pregate, postgate, keep=False):
+def _big_kernel_fft(mod, k):
+    """k (h, Lk) -> inner k_f rows (h * prod(N0), kf_elems, 2), head-major (heads can be sharded / gathered along dim 0)"""
+    ops = _TorchOps(mod, k.device)
+    return _big.kernel_fft(ops, mod.dtype, mod.seqlen, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1])
+
+
+def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None):
     """keep (training, module.save_spectrum): also return what the backward pass would otherwise compute again -- the
     transformed input x of the inner size (pair-plane rows), the inner spectra z (inner plans with that path) and, for the
-    gated form, the inner output y (dpostgate = its inverse levels * dout)."""
+    gated form, the inner output y (dpostgate = its inverse levels * dout).  kf: inner k_f rows computed elsewhere
+    (_big_kernel_fft; the B-shard gathers them from the ranks), k is then unused."""
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = _big.BIG_FACTORS[N][1]
-    kf = _big.kernel_fft(ops, dt, N, k.detach().to(torch.float32).contiguous(), H, k.shape[-1])
+    if kf is None:
+        kf = _big_kernel_fft(mod, k)
     x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
     z = None
     if keep:
@@ -227,7 +239,19 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False):
     return out, kf, ((x, z, y if pregate is not None else None) if keep else None)
 
 
-def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None):
+def _big_dk_from_dkf(mod, dkf, k_len):
+    """summed inner dk_f rows (h * prod(N0), kf_elems, 2) fp32 (one slab) -> dk (h, k_len) fp32"""
+    ops = _TorchOps(mod, dkf.device)
+    hp = dkf.shape[0]
+    h = hp
+    for n0 in _big.BIG_FACTORS[mod.seqlen][0]:
+        h //= n0
+    return _big.dk_from_slabs(ops, mod.seqlen, dkf.contiguous(), 2, h, k_len, nslab=1)
+
+
+def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dkf=False):
+    """want_dkf: return the fp32 inner dk_f rows summed over the local batch (hp, kf_elems, 2) instead of dk (B-shard: the
+    ranks reduce-scatter them and invert their own heads, _big_dk_from_dkf)"""
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
@@ -237,7 +261,14 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None):
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
     yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
-    dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
+    if want_dkf:
+        plan = ops._plan(M)
+        hp, nfl = xu.shape[1], xu.shape[1] * plan.kf_elems * 2
+        nslab = _lib.lib().ffc_dkf_slab_count(plan.handle, xu.shape[0], hp)
+        slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, hp, plan.kf_elems, 2)
+        dk = slabs[0] if nslab == 1 else slabs.sum(0)
+    else:
+        dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
     du = torch.empty_like(u)
     shared = {}
     _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared)

@@ -16,7 +16,7 @@ convolution's own backward).  y = x2 * conv(x1 * v, k): the same function as the
 import torch
 
 from . import _lib
-from .conv import FlashFFTConv, _check_inputs, _kernel_fft, _periodise_k
+from .conv import FlashFFTConv, _check_inputs, _kernel_fft, _periodise_k, _spectrum_buffer, _kf_key
 from .depthwise_1d import FlashDepthWiseConv1d
 
 
@@ -33,22 +33,41 @@ class _GatedSlicesFn(torch.autograd.Function):
         D = D3 // 3
         plan = mod._get_plan(uc.device, mod._plan_seqlen)
         with torch.cuda.device(uc.device):
-            kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
+            kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None      # inference cache, as FlashFFTConv
+            if kf is None:
+                kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
+                if mod.cache_kf and not k.requires_grad:
+                    mod._kf_cache = (_kf_key(k), kf)
             y = torch.empty(B, D, L, dtype=uc.dtype, device=uc.device)
             sb = D3 * L
-            _lib.check(_lib.lib().ffc_conv_fwd_strided(plan.handle, _slice_ptr(uc, 2, D, L), _lib.ptr(kf), _slice_ptr(uc, 0, D, L),
-                                                       _slice_ptr(uc, 1, D, L), _lib.ptr(y), B, D, L, 0, sb, sb, sb, 0,
-                                                       _lib.stream_ptr()), "ffc_conv_fwd_strided")
+            # training: keep the spectra FFT(x1 * v) and the output before the x2 multiply (FlashFFTConv.save_spectrum)
+            z = yraw = None
+            if mod.training and mod.save_spectrum and any(ctx.needs_input_grad[:2]):
+                z = _spectrum_buffer(plan, B, D, uc.device)
+                if z is not None:
+                    try:
+                        yraw = torch.empty_like(y)
+                    except torch.cuda.OutOfMemoryError:
+                        z = None
+            if z is None:
+                _lib.check(_lib.lib().ffc_conv_fwd_strided(plan.handle, _slice_ptr(uc, 2, D, L), _lib.ptr(kf), _slice_ptr(uc, 0, D, L),
+                                                           _slice_ptr(uc, 1, D, L), _lib.ptr(y), B, D, L, 0, sb, sb, sb, 0,
+                                                           _lib.stream_ptr()), "ffc_conv_fwd_strided")
+            else:
+                _lib.check(_lib.lib().ffc_conv_fwd_z(plan.handle, _slice_ptr(uc, 2, D, L), _lib.ptr(kf), _slice_ptr(uc, 0, D, L),
+                                                     _slice_ptr(uc, 1, D, L), _lib.ptr(y), _lib.ptr(z), _lib.ptr(yraw), B, D, L,
+                                                     sb, sb, sb, 0, _lib.stream_ptr()), "ffc_conv_fwd_z")
         ctx.mod, ctx.k_len, ctx.k_dtype = mod, k.shape[-1], k.dtype
         if mod.training:
-            ctx.save_for_backward(uc, kf)
+            ctx.save_for_backward(*((uc, kf) + (() if z is None else (z, yraw))))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if not ctx.saved_tensors:
             raise RuntimeError("FlashHyenaOp: backward needs module.training=True at forward time")
-        uc, kf = ctx.saved_tensors
+        uc, kf = ctx.saved_tensors[:2]
+        z, yraw = ctx.saved_tensors[2:4] if len(ctx.saved_tensors) > 2 else (None, None)
         mod = ctx.mod
         B, D3, L = uc.shape
         D = D3 // 3
@@ -60,7 +79,14 @@ class _GatedSlicesFn(torch.autograd.Function):
             ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, D), dtype=torch.uint8, device=uc.device)
             sb = D3 * L
             # u = v (slice 2), pregate = x1 (slice 0), postgate = x2 (slice 1); gradients land in the same slices of duc
-            _lib.check(lib.ffc_conv_bwd_gated_strided(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
+            if z is not None:
+                torch.mul(dy, yraw, out=duc.view(B, 3, D, L)[:, 1])         # d x2 = dy * (output before the x2 multiply)
+                _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
+                                              _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
+                                              _slice_ptr(duc, 0, D, L), None, _lib.ptr(ws), _lib.ptr(z), B, D, L,
+                                              0, sb, sb, sb, sb, sb, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
+            else:
+              _lib.check(lib.ffc_conv_bwd_gated_strided(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
                                                       _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
                                                       _slice_ptr(duc, 0, D, L), _slice_ptr(duc, 1, D, L), _lib.ptr(ws), B, D, L,
                                                       0, sb, sb, sb, sb, sb, sb, _lib.stream_ptr()), "ffc_conv_bwd_gated_strided")
@@ -81,7 +107,10 @@ def gated_conv_from_slices(conv, uc, k):
     if uc.dim() != 3 or uc.shape[1] % 3:
         raise RuntimeError("gated_conv_from_slices: uc must be (B, 3*D, L)")
     D, L = uc.shape[1] // 3, uc.shape[2]
-    if conv._big or conv._kf_keep is not None or (D * L) % 8 or not uc.is_contiguous():
+    # (the strided launchers address one tensor with 31-bit element offsets: (B-1) * 3*D*L + D*L has to stay below 2^31,
+    # where the composition on contiguous copies only needs B*D*L < 2^31)
+    too_wide = (uc.shape[0] - 1) * 3 * D * L + D * L >= 2 ** 31
+    if conv._big or conv._kf_keep is not None or (D * L) % 8 or not uc.is_contiguous() or too_wide:
         x1, x2, v = (t.contiguous() for t in uc.split(D, dim=1))
         return conv(v, k, x1, x2)
     _check_inputs(conv, uc[:, :D], k, ())

@@ -10,8 +10,10 @@ RCCL/xGMI (backend "nccl"); every (b, h) row is independent given k[h], so there
                                            REDUCE-SCATTERed, each rank inverts its H/W heads, dk is all-gathered so the
                                            replicated parameter gets the full gradient (what DDP's all-reduce would give).
                                  mode="recompute" skips the k_f exchange (every rank runs the whole FFT(k), dk is
-                                 all-reduced): cheaper than the collective's latency for short fft sizes, and the only mode
-                                 for fft sizes >= 65536.
+                                 all-reduced): cheaper than the collective's latency for short fft sizes.  The exchange mode
+                                 covers every fft size: the multi-pass plans (65536, 131072) are fused plans like the
+                                 smaller ones, the HBM-level sizes (>= 262144) exchange the rows of their inner size
+                                 (_BigOps); only the folded and the frequency-sparse forms fall back to recompute.
 
 The compute goes through an `ops` object (GPU: _HipOps over the C-ABI; CPU tests: a torch.fft stand-in) so the collective
 logic is exercised by world_size-2 gloo tests without a GPU.  The reference has no distributed code; this is new."""
@@ -40,7 +42,9 @@ def _all_gather_uneven(x_local, H, dim, group=None):
     m = max(sizes)
     if all(s == m for s in sizes) and dim == 0 and x_local.is_contiguous():
         out = x_local.new_empty((H,) + tuple(x_local.shape[1:]))
-        dist.all_gather_into_tensor(out, x_local, group=group) if dist.get_backend(group) == "nccl" else \
+        try:        # one tensor collective (RCCL; gloo has it for CPU tensors)
+            dist.all_gather_into_tensor(out, x_local, group=group)
+        except (RuntimeError, NotImplementedError):
             dist.all_gather(list(out.chunk(world, 0)), x_local, group=group)
         return out
     pad_shape = list(x_local.shape); pad_shape[dim] = m
@@ -56,13 +60,24 @@ def _reduce_scatter_heads(x_full, dim, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     H = x_full.shape[dim]
     s, e = head_range(H, rank, world)
-    if dist.get_backend(group) == "nccl" and H % world == 0 and dim == 0 and x_full.is_contiguous():
+    if H % world == 0 and dim == 0 and x_full.is_contiguous():
         out = x_full.new_empty((H // world,) + tuple(x_full.shape[1:]))
-        dist.reduce_scatter_tensor(out, x_full, group=group)
-        return out
+        try:        # one tensor collective (RCCL; gloo has it for CPU tensors)
+            dist.reduce_scatter_tensor(out, x_full, group=group)
+            return out
+        except (RuntimeError, NotImplementedError):
+            pass
     x = x_full.clone()
     dist.all_reduce(x, group=group)          # gloo (CPU tests / same-GPU tests) and uneven shards
     return x.narrow(dim, s, e - s).contiguous()
+
+
+def _all_gather_rows(x_local, H, rows, group=None):
+    """all-gather of head shards whose dim 0 is (head, row) with `rows` rows per head"""
+    if rows == 1:
+        return _all_gather_uneven(x_local, H, 0, group)
+    full = _all_gather_uneven(x_local.reshape((-1, rows) + tuple(x_local.shape[1:])), H, 0, group)
+    return full.reshape((H * rows,) + tuple(x_local.shape[1:]))
 
 
 class _GatherHeads(torch.autograd.Function):
@@ -112,21 +127,37 @@ class _HipOps:
         self.plan = mod._get_plan(device, mod._plan_seqlen)
 
     def kernel_fft(self, k):                       # (h, Lk) fp32 -> (h, kf_elems, 2) dtype, internal order
+        if k.shape[0] == 0:                        # more ranks than heads: an empty shard
+            return torch.empty(0, self.plan.kf_elems, 2, dtype=self.plan.dtype, device=k.device)
         return self.C._kernel_fft(self.plan, k)
 
     def conv(self, u, kf, pre, post):
         return self.C._conv(self.plan, u, kf, pre, post, False)
 
-    def backward(self, dout, u, kf, pre, post):
+    def conv_keep(self, u, kf, pre, post):
+        """training forward: (out, kept) with kept = (spectra, output before the postgate) or None (FlashFFTConv.save_spectrum)"""
+        z = self.C._spectrum_buffer(self.plan, u.shape[0], u.shape[1], u.device) if self.mod.save_spectrum else None
+        if z is None:
+            return self.conv(u, kf, pre, post), None
+        yraw = torch.empty_like(u) if pre is not None else None
+        return self.C._conv_save(self.plan, u, kf, pre, post, z, yraw), (z, yraw)
+
+    def backward(self, dout, u, kf, pre, post, kept=None):
         """-> du, dpre, dpost, dk_f (H, kf_elems, 2) fp32 summed over the local batch"""
         lib, L = self.L.lib(), self.L
         B, H, Lu = u.shape
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(self.plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if pre is not None else None
-        dpost = torch.empty_like(u) if pre is not None else None
-        L.check(lib.ffc_conv_bwd_gated(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du),
-                                       L.ptr(dpre), L.ptr(dpost), L.ptr(ws), B, H, Lu, L.stream_ptr()), "ffc_conv_bwd_gated")
+        if kept is not None:
+            z, yraw = kept
+            dpost = dout * yraw if pre is not None else None
+            L.check(lib.ffc_conv_bwd_z(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du), L.ptr(dpre),
+                                       None, L.ptr(ws), L.ptr(z), B, H, Lu, 0, 0, 0, 0, 0, 0, 0, L.stream_ptr()), "ffc_conv_bwd_z")
+        else:
+            dpost = torch.empty_like(u) if pre is not None else None
+            L.check(lib.ffc_conv_bwd_gated(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du),
+                                           L.ptr(dpre), L.ptr(dpost), L.ptr(ws), B, H, Lu, L.stream_ptr()), "ffc_conv_bwd_gated")
         nslab = lib.ffc_dkf_slab_count(self.plan.handle, B, H)
         nfl = H * self.plan.kf_elems * 2
         slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, H, self.plan.kf_elems, 2)
@@ -136,9 +167,46 @@ class _HipOps:
         L = self.L
         h = dkf.shape[0]
         dk = torch.empty(h, Lk, dtype=torch.float32, device=dkf.device)
+        if h == 0:
+            return dk
         L.check(L.lib().ffc_kernel_ifft_grad_slabs(self.plan.handle, L.ptr(dkf.contiguous()), 1, h, Lk, L.ptr(dk), L.stream_ptr()),
                 "ffc_kernel_ifft_grad_slabs")
         return dk
+
+
+class _BigOps:
+    """GPU backend of the B-shard for the HBM-level sizes (fft >= 262144): the exchanged tensors are the k_f / dk_f rows of
+    the inner size, `rows` per head (head-major), so the head partition carries over as a row partition."""
+
+    def __init__(self, mod, device):
+        from . import conv as C, bigfft
+        self.C, self.mod = C, mod
+        factors, self.M = bigfft.BIG_FACTORS[mod.seqlen]
+        self.rows = 1
+        for n0 in factors:
+            self.rows *= n0
+
+    def kernel_fft(self, k):
+        if k.shape[0] == 0:                        # more ranks than heads: an empty shard
+            plan = self.mod._get_plan(k.device, self.M)
+            return torch.empty(0, plan.kf_elems, 2, dtype=self.mod.dtype, device=k.device)
+        return self.C._big_kernel_fft(self.mod, k)
+
+    def conv(self, u, kf, pre, post):
+        return self.C._big_forward(self.mod, u, None, pre, post, False, kf)[0]
+
+    def conv_keep(self, u, kf, pre, post):
+        out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, bool(self.mod.save_spectrum), kf)
+        return out, kept
+
+    def backward(self, dout, u, kf, pre, post, kept=None):
+        du, dkf, dpre, dpost = self.C._big_backward(self.mod, dout, u, kf, pre, post, 0, kept, True)
+        return du, dpre, dpost, dkf
+
+    def dk_from_dkf(self, dkf, Lk):
+        if dkf.shape[0] == 0:
+            return torch.empty(0, Lk, dtype=torch.float32, device=dkf.device)
+        return self.C._big_dk_from_dkf(self.mod, dkf, Lk)
 
 
 class _BShardFn(torch.autograd.Function):
@@ -147,31 +215,47 @@ class _BShardFn(torch.autograd.Function):
         H, Lk = k.shape
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         s, e = head_range(H, rank, world)
-        kf_local = ops.kernel_fft(k.detach()[s:e].to(torch.float32).contiguous())
-        kf = _all_gather_uneven(kf_local, H, 0, group)                # the path's one forward collective
+        rows = getattr(ops, "rows", 1)          # exchanged rows per head (1 for the fused plans)
+        kf_local = ops.kernel_fft(k.detach()[s:e].to(torch.float32).contiguous())      # (an empty shard when H < world)
+        kf = _all_gather_rows(kf_local, H, rows, group)                # the path's one forward collective
         u = u.contiguous()
         pre = None if pre is None else pre.contiguous()
         post = None if post is None else post.contiguous()
-        out = ops.conv(u, kf, pre, post)
-        ctx.ops, ctx.group, ctx.Lk, ctx.k_dtype, ctx.gated = ops, group, Lk, k.dtype, pre is not None
+        kept = None
+        if training and hasattr(ops, "conv_keep"):
+            out, kept = ops.conv_keep(u, kf, pre, post)
+        else:
+            out = ops.conv(u, kf, pre, post)
+        ctx.kept_layout = None if kept is None else tuple(t is not None for t in kept)
+        ctx.ops, ctx.group, ctx.Lk, ctx.k_dtype, ctx.gated, ctx.H, ctx.rows = ops, group, Lk, k.dtype, pre is not None, H, rows
         if training:
-            ctx.save_for_backward(*((u, kf, pre, post) if pre is not None else (u, kf)))
+            extra = () if kept is None else tuple(t for t in kept if t is not None)
+            ctx.save_for_backward(*(((u, kf, pre, post) if pre is not None else (u, kf)) + extra))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.saved_tensors:
             raise RuntimeError("BatchShardedFFTConv: backward needs module.training=True at forward time")
+        nb = 4 if ctx.gated else 2
         if ctx.gated:
-            u, kf, pre, post = ctx.saved_tensors
+            u, kf, pre, post = ctx.saved_tensors[:4]
         else:
-            (u, kf), pre, post = ctx.saved_tensors, None, None
+            (u, kf), pre, post = ctx.saved_tensors[:2], None, None
+        kept = None
+        if ctx.kept_layout is not None:
+            it = iter(ctx.saved_tensors[nb:])
+            kept = tuple(next(it) if present else None for present in ctx.kept_layout)
         import contextlib
         with (torch.cuda.device(u.device) if u.is_cuda else contextlib.nullcontext()):
-            du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post)
-            H = dkf.shape[0]
-            dkf_local = _reduce_scatter_heads(dkf.contiguous(), 0, ctx.group)   # fp32 sums over every rank's batch rows
-            dk_local = ctx.ops.dk_from_dkf(dkf_local, ctx.Lk)
+            if kept is not None:
+                du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post, kept)
+            else:
+                du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post)
+            H, rows = ctx.H, ctx.rows
+            # fp32 sums over every rank's batch rows; (H, rows, ...) view so that the partition is the head partition
+            dkf_local = _reduce_scatter_heads(dkf.contiguous().view((H, rows) + tuple(dkf.shape[1:])), 0, ctx.group)
+            dk_local = ctx.ops.dk_from_dkf(dkf_local.reshape((-1,) + tuple(dkf.shape[1:])), ctx.Lk)
             dk = _all_gather_uneven(dk_local, H, 0, ctx.group)        # replicated parameter -> full gradient everywhere
         return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None
 
@@ -206,13 +290,12 @@ class BatchShardedFFTConv(torch.nn.Module):
             assert pregate is not None and postgate is not None
         mode = self.mode
         if self._ops is None and mode == "allgather_kf":
-            from . import bigfft
-            if self.conv._big or self.conv._folded or self.conv._kf_keep is not None:
-                mode = "recompute"          # k_f of these sizes is not a single fused plan's tensor
+            if self.conv._folded or self.conv._kf_keep is not None:
+                mode = "recompute"          # (periodised k / masked k_f: not worth an exchange path of their own)
         if mode == "recompute":
             kk = _AllReduceGrad.apply(k, self.group)
             return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
-        ops = self._ops if self._ops is not None else _HipOps(self.conv, u.device)
+        ops = self._ops if self._ops is not None else (_BigOps if self.conv._big else _HipOps)(self.conv, u.device)
         training = self.conv.training if hasattr(self.conv, "training") else True
         if self._ops is None:
             from .conv import _check_inputs

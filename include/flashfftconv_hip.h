@@ -121,6 +121,9 @@ int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int d
 /* complex-input k_f and complex-output dk variants used by the big sizes (pair-plane tensors (2,H,N)). */
 int ffc_kernel_fft_c(const ffc_plan* plan, const void* xpair, int64_t H, void* kf_out, float scale, void* stream);
 int ffc_kernel_ifft_grad_c(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream);
+/* ... from `nslab` caller-owned fp32 slabs [nslab][H][kf_elems][2] (multi-GPU B-shard: rows reduce-scattered over the ranks) */
+int ffc_kernel_ifft_grad_c_slabs(const ffc_plan* plan, const void* slabs, int64_t nslab, int64_t H, void* outpair, float scale,
+                                 void* stream);
 
 /* Short depthwise conv1d (reference csrc/flashfftconv/conv1d/conv1d.h:48-95).
  * in_dtype / w_dtype: 0 bf16, 1 fp16, 2 fp32.  is_bhl: u (B,D,L) w (D,K) else u (B,L,D) w (K,D). */

@@ -38,7 +38,7 @@ def _body(rank, world, port, q):
     ok = {}
     dev = torch.device("cuda", 0)
     for (N, B, H, L, gated) in ((4096, 4, 16, 2048, False), (32768, 4, 10, 16384, True), (1024, 8, 7, 1024, False),
-                                (65536, 4, 6, 32768, False)):
+                                (65536, 4, 6, 32768, False), (262144, 4, 6, 131072, False), (524288, 4, 4, 262144, True)):
         torch.manual_seed(7)                      # same inputs on both ranks
         dt = torch.bfloat16
         mk = lambda: torch.randn(B, H, L, device=dev).to(dt)
@@ -68,16 +68,23 @@ def _body(rank, world, port, q):
         for mode in (("allgather_kf", "recompute") if N <= 32768 else ("allgather_kf",)):
             bs = BatchShardedFFTConv(mod, mode=mode)
             yl = bs(*bv)
-            ok[f"{tag}_bshard_{mode}_out_bitwise"] = torch.equal(yl, full[b0:b1])
+            # bitwise where a pair meets the same kernel code alone as in the full batch; the inner sizes 8192 / 16384 run two
+            # pairs of a head in lock-step when they have them (Body::inner_tile2x) and one pair alone otherwise: same
+            # arithmetic, the compiler contracts it differently, results move by single steps of the dtype
+            same = (lambda a, b: torch.equal(a, b)) if N < 262144 else (lambda a, b: rel(a, b) < 4e-3)
+            ok[f"{tag}_bshard_{mode}_out_bitwise"] = same(yl, full[b0:b1])
             gl = torch.autograd.grad(yl, bv, dout[b0:b1])
-            ok[f"{tag}_bshard_{mode}_du_bitwise"] = torch.equal(gl[0], gfull[0][b0:b1])
+            ok[f"{tag}_bshard_{mode}_du_bitwise"] = same(gl[0], gfull[0][b0:b1])
             # FULL dk on every rank.  allgather_kf: one inverse of the reduced fp32 sums, like the single-rank run;
             # recompute: each rank inverts ITS partial sums (bf16 operands, 2^-9) and the results are all-reduced
-            dk_tol = 2e-3 if (mode == "allgather_kf" and N <= 32768) else 8e-3
+            dk_tol = 2e-3 if (mode == "allgather_kf" and N <= 32768) else 8e-3 if N <= 131072 else 1.6e-2
             ok[f"{tag}_bshard_{mode}_dk_vs_single"] = rel(gl[1], gfull[1]) < dk_tol
             ok[f"{tag}_bshard_{mode}_dk_vs_oracle"] = rel(gl[1], goref[1]) < 3e-2
             if gated:
-                ok[f"{tag}_bshard_{mode}_dgates_bitwise"] = torch.equal(gl[2], gfull[2][b0:b1]) and torch.equal(gl[3], gfull[3][b0:b1])
+                ok[f"{tag}_bshard_{mode}_dgates_bitwise"] = same(gl[2], gfull[2][b0:b1]) and same(gl[3], gfull[3][b0:b1])
+        if N >= 262144:      # fft sizes with HBM levels exchange the k_f / dk_f rows of their inner size too (no silent recompute)
+            from flashfftconv import sharding as SH
+            ok[f"{tag}_bshard_exchanges_rows"] = isinstance((SH._BigOps if mod._big else SH._HipOps)(mod, dev), SH._BigOps)
     q.put((rank, ok))
     dist.destroy_process_group()
 
