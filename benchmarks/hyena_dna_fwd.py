@@ -11,7 +11,11 @@ returns the k_ones buffer, :190-201).  The Hyena operator comes in three forms:
    torch    the reference's non-flash path: nn.Conv1d + torch.fft (hyenadna_standalone.py fftconv)
 Prints one JSON line per (config, form): ms per forward, tokens/ms, seqs/s (the reference prints the same three numbers),
 and the relative difference of the output to the torch form.
-usage: python benchmarks/hyena_dna_fwd.py [tiny-16k small-32k medium-160k large-1m]"""
+The config `hyena-pile-4k` is the port of the reference's third caller bench, examples/hyena/benchmark_fwd.py (a hydra /
+lightning harness around `model.model.backbone(input_ids)`, :665-680) on its sample config experiment/pile/hyena-flashfft.yaml:
+the 153M Hyena LM backbone (d_model 864, 18 layers, d_inner = 2 d_model, l_max 4096, batch 8, fp16) in inference mode (the
+long filter is loaded, not generated: examples/hyena/README.md), same three printed numbers.
+usage: python benchmarks/hyena_dna_fwd.py [tiny-16k small-32k medium-160k large-1m hyena-pile-4k]"""
 import json, math, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "flash-fft-conv_amd"), ROOT]
@@ -20,9 +24,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d, FlashHyenaOp
 
-# name: (d_model, n_layer, max_length, batch)   -- sizes of the published HyenaDNA checkpoints (huggingface.py:160-175)
+# name: (d_model, n_layer, max_length, batch[, d_inner / d_model, dtype])   -- sizes of the published HyenaDNA checkpoints
+# (huggingface.py:160-175) and the Hyena LM of examples/hyena/configs/experiment/pile/hyena.yaml
 CONFIGS = {"tiny-16k": (128, 2, 16384, 4), "small-32k": (256, 4, 32768, 4), "medium-160k": (256, 8, 131072, 4),
-           "medium-450k": (256, 8, 450000, 2), "large-1m": (256, 8, 1000000, 2)}
+           "medium-450k": (256, 8, 450000, 2), "large-1m": (256, 8, 1000000, 2),
+           "hyena-pile-4k": (864, 18, 4096, 8, 2, torch.float16)}
 
 
 def fft_size_for(L):
@@ -80,14 +86,14 @@ class HyenaOperator(nn.Module):
 
 
 class Backbone(nn.Module):
-    def __init__(self, d_model, n_layer, l_max, form, dtype, vocab=16):
+    def __init__(self, d_model, n_layer, l_max, form, dtype, vocab=16, inner=4):
         super().__init__()
         self.emb = nn.Embedding(vocab, d_model)
         self.layers = nn.ModuleList()
         for _ in range(n_layer):
             self.layers.append(nn.ModuleDict(dict(
                 n1=nn.LayerNorm(d_model), mixer=HyenaOperator(d_model, l_max, form, dtype), n2=nn.LayerNorm(d_model),
-                fc1=nn.Linear(d_model, 4 * d_model), fc2=nn.Linear(4 * d_model, d_model))))
+                fc1=nn.Linear(d_model, inner * d_model), fc2=nn.Linear(inner * d_model, d_model))))
         self.ln_f = nn.LayerNorm(d_model)
 
     def forward(self, ids):
@@ -111,12 +117,14 @@ def ev_time(fn, iters):
 
 
 def run(name, dtype=torch.bfloat16):
-    d_model, n_layer, L, B = CONFIGS[name]
+    d_model, n_layer, L, B = CONFIGS[name][:4]
+    inner = CONFIGS[name][4] if len(CONFIGS[name]) > 4 else 4
+    dtype = CONFIGS[name][5] if len(CONFIGS[name]) > 5 else dtype
     ids = torch.randint(0, 12, (B, L), device="cuda")
     outs = {}
     for form in ("torch", "dropin", "fused"):
         torch.manual_seed(0)
-        model = Backbone(d_model, n_layer, L, form, dtype).cuda().to(dtype).eval()
+        model = Backbone(d_model, n_layer, L, form, dtype, inner=inner).cuda().to(dtype).eval()
         for m in model.modules():                    # the long filter stays fp32 (the reference passes fp32 k to FlashFFTConv)
             if isinstance(m, HyenaOperator):
                 m.k = m.k.float()

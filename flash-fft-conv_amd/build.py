@@ -68,6 +68,12 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
     variant: tuning build with `extra_flags` under lib/variants/<name>/ (A/B runs: FFC_LIB=<that .so>)."""
     from concurrent.futures import ThreadPoolExecutor
     global HIP_FLAGS
+    # knock-out / experiment switches (FFC_KO, FFC_EXP_*, FFC_NO_SETTLE, ...) produce wrong or unguarded results by design: they
+    # may only go into a named variant under lib/variants/, never into the library the package loads
+    risky = [f for f in list(extra_flags) + os.environ.get("HIPCC_EXTRA_FLAGS", "").split()
+             if f.startswith("-DFFC_KO") or f.startswith("-DFFC_EXP_") or f.startswith("-DFFC_NO_SETTLE") or f.startswith("-DFFC_BWD_PROF")]
+    if variant is None and (risky or extra_flags):
+        raise RuntimeError(f"build.py: extra flags {list(extra_flags)} are only accepted with --variant NAME (the default target is the product)")
     lib_dir = LIB if variant is None else os.path.join(LIB, "variants", variant)
     os.makedirs(lib_dir, exist_ok=True)
     obj_dir = os.path.join(lib_dir, "obj")
