@@ -20,11 +20,18 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(12
     Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
   }
 }
+// single-tile sizes (fft <= 2048): persistent workgroups (two per CU) walk the (head, chunk) jobs, the plan tables are copied
+// to LDS once per workgroup instead of once per job (a job is one pair per wave at B = 16: the copy was as large as the work)
 template <class GEO, int DT>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel_small(DkfArgs d) {
-  int h, chunk;
-  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevB, GEO, DT>::template bwd<false>(d, h, chunk, blockIdx.x);
+  using M = Modes<DevB, GEO, DT>;
+  M::BD::setup_tables(d.c.tab, d.c.t);
+  if constexpr (GEO::N == 1024) { if (d.c.R > 1) M::BD::setup_tables_ipass(d.c.tab, d.c.t, d.c.R); }
+  const int total = ((d.c.H + 7) & ~7) * d.c.nchunk;
+  for (int id = blockIdx.x; id < total; id += gridDim.x) {
+    int h, chunk;
+    if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) M::template bwd<false, false, false>(d, h, chunk, id);
+  }
 }
 template <class GEO, int DT, bool HALF>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_rp_kernel(DkfArgs d) {
@@ -67,7 +74,8 @@ struct BwdLaunch {
       static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
       if (rc) return rc;
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
-      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), grid, block, lds, st, d);
+      const int cap = (d.c.persist > 0 && d.c.persist < (1 << 29)) ? 2 * d.c.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
+      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), dim3(ngrid > cap ? cap : ngrid), block, lds, st, d);
     } else {
       const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
       if (half) {

@@ -3,8 +3,11 @@
 using namespace ffc;
 
 // SZ: the forward that also stores the pairs' spectra for the backward pass (ConvArgs::zsave; fused sizes with an outer digit)
+#ifndef FFC_SMALL_WAVES
+#define FFC_SMALL_WAVES 2
+#endif
 template <class GEO, int DT, bool HALF, bool SZ = false>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) void conv_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
 #if defined(FFC_SETPRIO)
   // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "two waves per SIMD" item 4)
@@ -15,6 +18,15 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
     // the grid (a multiple of 8, so a workgroup's heads stay on its XCD).  No phase of these units needs a
     // workgroup barrier (Body::unit_barrier), so the eight waves drift apart across jobs: one wave's row loads and
     // stores overlap another's transforms, and the plan tables are copied to LDS once per CU instead of once per head.
+    BD::setup_tables(a.tab, a.t);
+    const int total = ((a.H + 7) & ~7) * a.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF, false, SZ>(a, h, chunk);
+    }
+  } else if constexpr (!GEO::OUTER) {
+    // single-tile sizes (fft <= 1024): persistent workgroups too (two per CU): a job is one tile per wave, copying the plan
+    // tables to LDS for every job cost as much as the job
     BD::setup_tables(a.tab, a.t);
     const int total = ((a.H + 7) & ~7) * a.nchunk;
     for (int id = blockIdx.x; id < total; id += gridDim.x) {
@@ -34,11 +46,21 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_kernel(ConvArgs a) {
 template <class GEO, int DT, bool HALF, bool SZ = false>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) void conv_rp_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
-  int h, chunk;
-  if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
-  BD::setup_tables(a.tab, a.t);
-  if constexpr (!GEO::OUTER) BD::setup_tables_ipass(a.tab, a.t, a.R);     // inner-only form (fft 2048): per-pass tables
-  BD::template conv_job<HALF, true, SZ>(a, h, chunk);
+  if constexpr (!GEO::OUTER) {
+    // inner-only form (fft 2048): persistent workgroups, tables (incl. the per-pass ones) copied once
+    BD::setup_tables(a.tab, a.t);
+    BD::setup_tables_ipass(a.tab, a.t, a.R);
+    const int total = ((a.H + 7) & ~7) * a.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF, true, SZ>(a, h, chunk);
+    }
+  } else {
+    int h, chunk;
+    if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
+    BD::setup_tables(a.tab, a.t);
+    BD::template conv_job<HALF, true, SZ>(a, h, chunk);
+  }
 }
 
 template <class GEO, int DT>
@@ -77,7 +99,8 @@ struct ConvLaunch {
         constexpr int lds = GEO::LDS_BYTES + 2 * BD::IPASS_BYTES;
         static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
+        const int cap = (a.persist > 0 && a.persist < (1 << 29)) ? 2 * a.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
+        hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else {
@@ -85,6 +108,7 @@ struct ConvLaunch {
       }
     }
     if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
+    if (!GEO::OUTER && a.persist > 0 && a.persist < (1 << 29) && grid > 2 * a.persist) grid = 2 * a.persist;      // persistent: two per CU
     if (a.zsave) {
       if constexpr (GEO::OUTER) {
         if ((GEO::N1 / 2) * GEO::Mi >= a.L) {

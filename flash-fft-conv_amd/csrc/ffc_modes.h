@@ -761,7 +761,8 @@ struct Modes : Body<B, GEO, DT> {
     }
     BD::cmul_conj(re, im, k);
   }
-  template <bool HALF = false, bool RP = false>
+  // SETUP = false: the plan tables are already in LDS (persistent workgroups of the single-tile sizes copy them once)
+  template <bool HALF = false, bool RP = false, bool SETUP = true>
   static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear, int k0 = 0, int wv_in = 0) {
     const ConvArgs& a = d.c;
     const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
@@ -769,7 +770,7 @@ struct Modes : Body<B, GEO, DT> {
     constexpr int NCX = HALF ? BD::NCH / 2 : BD::NCH;
     // multi-pass kernels copy the tables and read the wave index once, before their pass loop (nothing derived from the
     // work-item id stays live across the passes: on the 128-VGPR budget it would be parked in an accumulation register)
-    if constexpr (!RP) BD::setup_tables(a.tab, a.t);
+    if constexpr (!RP && SETUP) BD::setup_tables(a.tab, a.t);
     const int wv = RP ? wv_in : B::wave();
     Unit un;
     un.wq = wv % GEO::NW;
@@ -945,7 +946,7 @@ struct Modes : Body<B, GEO, DT> {
     } else if (a.R > 1) {
       // inner-only multi-pass form: pass-major; du / dpregate accumulate over the passes (rows_out_rp)
       if constexpr (GEO::N == 1024) {
-        BD::setup_tables_ipass(a.tab, a.t, a.R);
+        if constexpr (SETUP) BD::setup_tables_ipass(a.tab, a.t, a.R);
         const int q0 = p0, q1 = p1;
         const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
         BD::load_inner(R, un);
