@@ -36,11 +36,41 @@ extern "C" int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, in
   if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
   a.Bp_valid = (int)Bv; a.npair = (int)npair; a.Hin = (int)Hin; a.Mi = (int)Mi; a.Llong = (int)Llong; a.scale = scale;
   a.fast = (Llong % 8 == 0) && !(((uintptr_t)in | (uintptr_t)out | (uintptr_t)gate) & 15);
+  a.R = 1; a.c = 0;
   hipStream_t st = (hipStream_t)stream;
   if (n0 == 16) {
     if (bf) return dir ? launch_big<16, DT_BF16, true>(a, st) : launch_big<16, DT_BF16, false>(a, st);
     return dir ? launch_big<16, DT_F16, true>(a, st) : launch_big<16, DT_F16, false>(a, st);
   }
+  if (bf) return dir ? launch_big<32, DT_BF16, true>(a, st) : launch_big<32, DT_BF16, false>(a, st);
+  return dir ? launch_big<32, DT_F16, true>(a, st) : launch_big<32, DT_F16, false>(a, st);
+}
+
+// One level of factor R * 32 as R passes of the 32-point kernel (BigArgs::R): fft 4194304 = 128 x 32768 in ONE HBM level when
+// the long side is at most a quarter of it (Llong <= 32 * Mi, the HyenaDNA shape L = N / 4), instead of two levels of 16
+// (the reference runs 4M in one level with its 128-point butterfly: csrc/flashfftconv/butterfly/butterfly_padded_cuda_bf16.cu
+// :302-487, conv.py:511-551).  `plan_r`: a multi-pass plan with the same R and a 32-point outer digit (fft 131072 for R = 4):
+// its per-pass outer-digit tables are the matrices needed here.  dir = 1: every pass reads the long side and writes its
+// 32 rows of the R * 32 per head; dir = 0: pass c reads its rows, passes c > 0 add to the long side (call them in order).
+// An output gate (dir = 0) multiplies every pass's contribution before it is added: the same product, distributed over the sum.
+extern "C" int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int dir, const void* in, void* out, const void* gate,
+                                int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream) {
+  const ffc_plan* p = plan_r;
+  if (!p || !in || !out) return ffc_fail("null arg");
+  if (p->hp.N1 != 32 || p->hp.R < 2) return ffc_fail("outer pass (R passes): needs a multi-pass plan with a 32-point outer digit");
+  const int R = p->hp.R;
+  if (c < 0 || c >= R) return ffc_fail("outer pass (R passes): bad pass index");
+  if (Mi % GeoBig<32>::Mi) return ffc_fail("outer pass: Mi must be a multiple of the column block");
+  if (Llong <= 0 || Llong > 32 * Mi) return ffc_fail("outer pass (R passes): the long side must fit the first 32 rows (L <= N / R)");
+  BigArgs a{};
+  a.in = in; a.out = out; a.gate = gate;
+  const bool bf = dtype == DT_BF16;
+  if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
+  a.fmat = (bf ? p->d_blob_bf : p->d_blob) + (bf ? p->hp_bf.tabs.matk[c][dir ? 0 : 1] : p->hp.tabs.matk[c][dir ? 0 : 1]);
+  a.Bp_valid = (int)Bv; a.npair = (int)npair; a.Hin = (int)Hin; a.Mi = (int)Mi; a.Llong = (int)Llong; a.scale = scale;
+  a.fast = (Llong % 8 == 0) && !(((uintptr_t)in | (uintptr_t)out | (uintptr_t)gate) & 15);
+  a.R = R; a.c = c;
+  hipStream_t st = (hipStream_t)stream;
   if (bf) return dir ? launch_big<32, DT_BF16, true>(a, st) : launch_big<32, DT_BF16, false>(a, st);
   return dir ? launch_big<32, DT_F16, true>(a, st) : launch_big<32, DT_F16, false>(a, st);
 }

@@ -479,12 +479,21 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
 
 
 // HBM-level outer pass (ffc_big.h).  fwd: in = long side (Bp_valid rows, Hin, Llong), out = (2*npair, Hin*N0, Mi).
+int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in, void* out, const void* gate, int Bp_valid, int npair,
+                       int Hin, int Mi, int Llong, float scale);
 int ffcsim_big_outer(int N0, int dtype, int fwd, const void* in, void* out, const void* gate, int Bp_valid, int npair,
                      int Hin, int Mi, int Llong, float scale) {
+  return ffcsim_big_outer_r(N0, 1, 0, dtype, fwd, in, out, gate, Bp_valid, npair, Hin, Mi, Llong, scale);
+}
+// R > 1: pass c of a factor R * 32 (ffc_outer_pass_r; tables of the R-pass plan of the fused 32768 kernel)
+int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in, void* out, const void* gate, int Bp_valid, int npair,
+                       int Hin, int Mi, int Llong, float scale) {
   HostPlan p;
-  if (!build_plan(N0 == 16 ? 16384 : 32768, dtype, &p)) return -1;   // only for the N0-point operand table
+  if (R > 1 && N0 != 32) return -3;
+  if (!build_plan(R > 1 ? 32768 * R : (N0 == 16 ? 16384 : 32768), dtype, &p)) return -1;   // only for the N0-point operand table
   BigArgs a{};
-  a.in = in; a.out = out; a.gate = gate; a.fmat = p.blob.data() + p.tabs.mat[0];
+  a.R = R; a.c = c;
+  a.in = in; a.out = out; a.gate = gate; a.fmat = p.blob.data() + (R > 1 ? p.tabs.matk[c][fwd ? 0 : 1] : p.tabs.mat[0]);
   a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
   a.fast = (Llong % 8 == 0) && !g_force_slow;
   const int cols = N0 == 16 ? GeoBig<16>::Mi : GeoBig<32>::Mi;

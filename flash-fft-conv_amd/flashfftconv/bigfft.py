@@ -29,9 +29,23 @@ if _os.environ.get("FFC_BIG_1LEVEL", "0") == "1":
     BIG_FACTORS.update({2097152: ((32,), 65536), 4194304: ((32,), 131072)})
 
 
+# fft 4194304 in ONE level, 128 x 32768, when the long side is at most N / 4 (the HyenaDNA shape, BASELINE config 4): the
+# 128-point factor runs as 4 passes of the 32-point outer kernel (ops.outer with n0 = 128 -> ffc_outer_pass_r), each reading
+# the quarter-length rows and writing its 32 of the 128 rows per head -- one HBM round trip instead of two
+# (reference: the 128-point butterfly, butterfly_padded_cuda_bf16.cu:302-487, conv.py:511-551).  FFC_BIG_ONE128=0 disables it.
+ONE128 = {4194304: ((128,), 32768)} if _os.environ.get("FFC_BIG_ONE128", "1") != "0" else {}
+
+
+def choose(N, Lmax, ops=None):
+    """(outer factors, fused inner size) for fft size N when no long-side row is longer than Lmax"""
+    if N in ONE128 and Lmax <= N // 4 and getattr(ops, "HAS_128", False):
+        return ONE128[N]
+    return BIG_FACTORS[N]
+
+
 def level_scale(n0):
     """forward scale of one level ~ 1/sqrt(N0) (keeps the spectrum RMS near the input RMS)"""
-    return 0.25 if n0 == 16 else 0.125
+    return 0.25 if n0 == 16 else 0.125 if n0 == 32 else 0.0625
 
 
 def inner_sfwd(M):
@@ -40,9 +54,9 @@ def inner_sfwd(M):
     return 2.0 ** (-((lg + 1) // 2))
 
 
-def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None):
-    """x: (B_valid, H, L) long-side tensor -> (2*npair, H*prod(N0), M) pair-plane tensor."""
-    factors, M = BIG_FACTORS[N]
+def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None, fac=None):
+    """x: (B_valid, H, L) long-side tensor -> (2*npair, H*prod(N0), M) pair-plane tensor.  fac: choose(N, ...) (default: BIG_FACTORS)"""
+    factors, M = fac or BIG_FACTORS[N]
     npair = (B_valid + 1) // 2
     Hx, nlev, Llong, bv = H, N, L, B_valid
     for i, n0 in enumerate(factors):
@@ -53,10 +67,10 @@ def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None):
     return x
 
 
-def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None):
+def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None, fac=None):
     """y: (2*npair, H*prod(N0), M) -> out (B_valid, H, L) (written in place).  `shared` caches the
     intermediate of the two-level case so several gated outputs reuse it."""
-    factors, M = BIG_FACTORS[N]
+    factors, M = fac or BIG_FACTORS[N]
     npair = y.shape[0] // 2
     Hx = H
     for n0 in factors:
@@ -82,34 +96,34 @@ def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None):
     return out
 
 
-def prod_scale(N):
-    factors, M = BIG_FACTORS[N]
+def prod_scale(N, fac=None):
+    factors, M = fac or BIG_FACTORS[N]
     s = 1.0
     for n0 in factors:
         s *= level_scale(n0)
     return s
 
 
-def kernel_fft(ops, dt, N, k, H, Lk):
+def kernel_fft(ops, dt, N, k, H, Lk, fac=None):
     """k (H, Lk) fp32 -> inner k_f rows (H*prod(N0), M-internal), unscaled K_f."""
-    factors, M = BIG_FACTORS[N]
+    factors, M = fac or BIG_FACTORS[N]
     pre = ops.k_prescale(dt)                         # 2^8 in fp16 mode (k's energy sits in a few taps)
     kx = ops.to_dtype_rows(dt, k, H, Lk, pre)        # (1, H, Lk) dtype
-    x = levels_forward(ops, dt, N, kx, 1, H, Lk)
+    x = levels_forward(ops, dt, N, kx, 1, H, Lk, None, fac)
     hp = x.shape[1]
-    return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N) * pre))
+    return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre))
 
 
-def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None):
+def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None, fac=None):
     """fp32 W slabs of the inner size -> dk (H, Lk) fp32.  Always bf16 arithmetic (fp32 range).
     nslab: `ws` holds that many caller-owned slabs (hp, kf_elems, 2) instead of a backward launch's workspace."""
-    factors, M = BIG_FACTORS[N]
+    factors, M = fac or BIG_FACTORS[N]
     hp = H
     for n0 in factors:
         hp *= n0
     BF = ops.BF16
-    sc = 1.0 / (inner_sfwd(M) * prod_scale(N))
+    sc = 1.0 / (inner_sfwd(M) * prod_scale(N, fac))
     y = ops.dkifft_c(M, ws, Bp, hp, sc) if nslab is None else ops.dkifft_c(M, ws, Bp, hp, sc, nslab)     # (2, hp, M) bf16
     out = ops.empty_pair(BF, 1, H, Lk)
-    levels_inverse(ops, BF, N, y, out, 1, H, Lk)
+    levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac)
     return ops.to_float_rows(out, H, Lk)

@@ -144,7 +144,15 @@ class _TorchOps:
     def empty_pair(self, dt, Bp, Hx, n):
         return torch.empty(Bp, Hx, n, dtype=dt, device=self.device)
 
+    HAS_128 = True      # factor 128 as 4 passes of the 32-point kernel (bigfft.choose)
+
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+        if n0 == 128:
+            pr = self._plan(131072)      # the 4-pass plan: its per-pass outer-digit tables are the matrices of the passes
+            for c in range(4):
+                _lib.check(_lib.lib().ffc_outer_pass_r(pr.handle, c, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
+                                                       npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_r")
+            return
         p16, p32 = self._plan(16384), self._plan(32768)
         _lib.check(_lib.lib().ffc_outer_pass(p16.handle, p32.handle, n0, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out),
                                              _lib.ptr(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale),
@@ -211,13 +219,13 @@ class _TorchOps:
         return out
 
 
-def _big_kernel_fft(mod, k):
+def _big_kernel_fft(mod, k, fac=None):
     """k (h, Lk) -> inner k_f rows (h * prod(N0), kf_elems, 2), head-major (heads can be sharded / gathered along dim 0)"""
     ops = _TorchOps(mod, k.device)
-    return _big.kernel_fft(ops, mod.dtype, mod.seqlen, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1])
+    return _big.kernel_fft(ops, mod.dtype, mod.seqlen, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1], fac)
 
 
-def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None):
+def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
     """keep (training, module.save_spectrum): also return what the backward pass would otherwise compute again -- the
     transformed input x of the inner size (pair-plane rows), the inner spectra z (inner plans with that path) and, for the
     gated form, the inner output y (dpostgate = its inverse levels * dout).  kf: inner k_f rows computed elsewhere
@@ -225,39 +233,39 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None):
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
-    M = _big.BIG_FACTORS[N][1]
+    M = (fac or _big.BIG_FACTORS[N])[1]
     if kf is None:
-        kf = _big_kernel_fft(mod, k)
-    x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate)
+        kf = _big_kernel_fft(mod, k, fac)
+    x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
     z = None
     if keep:
         y, z = ops.conv_save(dt, M, x, kf)
     else:
         y = ops.conv(dt, M, x, kf, False)
     out = torch.empty_like(u)
-    _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate)
+    _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate, None, fac)
     return out, kf, ((x, z, y if pregate is not None else None) if keep else None)
 
 
-def _big_dk_from_dkf(mod, dkf, k_len):
+def _big_dk_from_dkf(mod, dkf, k_len, fac=None):
     """summed inner dk_f rows (h * prod(N0), kf_elems, 2) fp32 (one slab) -> dk (h, k_len) fp32"""
     ops = _TorchOps(mod, dkf.device)
     hp = dkf.shape[0]
     h = hp
-    for n0 in _big.BIG_FACTORS[mod.seqlen][0]:
+    for n0 in (fac or _big.BIG_FACTORS[mod.seqlen])[0]:
         h //= n0
-    return _big.dk_from_slabs(ops, mod.seqlen, dkf.contiguous(), 2, h, k_len, nslab=1)
+    return _big.dk_from_slabs(ops, mod.seqlen, dkf.contiguous(), 2, h, k_len, nslab=1, fac=fac)
 
 
-def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dkf=False):
+def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dkf=False, fac=None):
     """want_dkf: return the fp32 inner dk_f rows summed over the local batch (hp, kf_elems, 2) instead of dk (B-shard: the
     ranks reduce-scatter them and invert their own heads, _big_dk_from_dkf)"""
     N, dt = mod.seqlen, mod.dtype
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
-    M = _big.BIG_FACTORS[N][1]
-    xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate)
-    xu, z, yu = kept if kept is not None else (_big.levels_forward(ops, dt, N, u, B, H, L, pregate), None, None)
+    M = (fac or _big.BIG_FACTORS[N])[1]
+    xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate, fac)
+    xu, z, yu = kept if kept is not None else (_big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac), None, None)
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
     yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
@@ -268,18 +276,18 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
         slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, hp, plan.kf_elems, 2)
         dk = slabs[0] if nslab == 1 else slabs.sum(0)
     else:
-        dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len)
+        dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len, None, fac)
     du = torch.empty_like(u)
     shared = {}
-    _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared)
+    _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared, fac)
     if pregate is None:
         return du, dk, None, None
     dpre = torch.empty_like(u)
-    _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared)
+    _big.levels_inverse(ops, dt, N, yd, dpre, B, H, L, u, shared, fac)
     if yu is None:
         yu = ops.conv(dt, M, xu, kf, False)
     dpost = torch.empty_like(u)
-    _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout)
+    _big.levels_inverse(ops, dt, N, yu, dpost, B, H, L, dout, None, fac)
     return du, dk, dpre, dpost
 
 
@@ -324,12 +332,14 @@ class _FlashFFTConvFn(torch.autograd.Function):
         kept = None
         if ctx.big:
             keep = mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+            # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
+            ctx.fac = fac = _big.choose(mod.seqlen, max(u.shape[-1], k.shape[-1]), _TorchOps)
             try:
-                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, keep)
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, keep, None, fac)
             except torch.cuda.OutOfMemoryError:
                 if not keep:
                     raise
-                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False)
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False, None, fac)
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
             kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None
@@ -387,7 +397,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if getattr(ctx, "kept_layout", None) is not None:
                 it = iter(ctx.saved_tensors[4 if ctx.gated else 2:])
                 kept = tuple(next(it) if present else None for present in ctx.kept_layout)
-            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len, kept)
+            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len, kept, False, ctx.fac)
             return du, dk.to(ctx.k_dtype), None, dpre, dpost
         plan = ctx.mod._get_plan(u.device, ctx.mod._plan_seqlen)
         B, H, L = u.shape

@@ -119,6 +119,11 @@ int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int d
                    const void* gate, int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale,
                    void* stream);
 /* complex-input k_f and complex-output dk variants used by the big sizes (pair-plane tensors (2,H,N)). */
+/* One level of factor R * 32 as R passes c = 0 .. R-1 of the 32-point kernel (fft 4194304 = 128 x 32768 in ONE level when the
+ * long side is at most N / R: plan_r = the multi-pass plan with that R, fft 131072 for R = 4).  dir = 0: call the passes in
+ * order (c > 0 adds its -- gated -- contribution to the long side). */
+int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int dir, const void* in, void* out, const void* gate, int64_t Bv,
+                     int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream);
 int ffc_kernel_fft_c(const ffc_plan* plan, const void* xpair, int64_t H, void* kf_out, float scale, void* stream);
 int ffc_kernel_ifft_grad_c(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream);
 /* ... from `nslab` caller-owned fp32 slabs [nslab][H][kf_elems][2] (multi-GPU B-shard: rows reduce-scattered over the ranks) */

@@ -115,7 +115,15 @@ class SimOps:
     def empty_pair(self, dt, Bp, Hx, n):
         return np.zeros((Bp, Hx, n), np.uint16)
 
+    HAS_128 = True
+
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+        if n0 == 128:        # factor 128 = 4 passes of the 32-point kernel (ffc_outer_pass_r)
+            for c in range(4):
+                rc = lib().ffcsim_big_outer_r(32, 4, c, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,
+                                              ctypes.c_float(scale))
+                assert rc == 0, rc
+            return
         rc = lib().ffcsim_big_outer(n0, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,
                                     ctypes.c_float(scale))
         assert rc == 0, rc

@@ -167,6 +167,33 @@ def test_big_sizes_through_outer_levels(N, L, B, gated):
     assert rel(dk, dkref) < 1.5e-2
 
 
+@pytest.mark.parametrize("L,B,gated", [(131072, 2, False), (100004, 1, True)])
+def test_one_level_of_128(L, B, gated):
+    """the factor-128 level (4 passes of the 32-point outer kernel, ffc_outer_pass_r: how fft 4194304 = 128 x 32768 runs when
+    L <= N / 4) on a size the simulator finishes: fft 524288 = 128 x 4096, L <= N / 4, forward (gated, ragged, odd batch) and dk."""
+    from flashfftconv import bigfft as BG
+    N, fac = 524288, ((128,), 4096)
+    rng = np.random.default_rng(L)
+    dt, H, M = 0, 1, 4096
+    ops = S.SimOps()
+    u, g1, g2, d = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.05).astype(np.float32)
+    ub, g1b, g2b, db = (S.to_bits(x, dt) for x in (u, g1, g2, d))
+    kf = BG.kernel_fft(ops, dt, N, k, H, L, fac)
+    x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None, fac)
+    assert x.shape == (2 * ((B + 1) // 2), H * 128, M)
+    y = ops.conv(dt, M, x, kf, False)
+    out = np.zeros_like(ub)
+    BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None, None, fac)
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype="bf16") if gated else O.ref_fft_conv(q(u, dt), k, N)
+    assert rel(S.from_bits(out, dt), ref) < 1.5e-2
+    xd = BG.levels_forward(ops, dt, N, db, B, H, L, None, fac)
+    xu = BG.levels_forward(ops, dt, N, ub, B, H, L, None, fac)
+    dk = BG.dk_from_slabs(ops, N, ops.dkf(dt, M, xd, xu), xu.shape[0], H, L, None, fac)
+    _, dkref = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(dk, dkref) < 1.5e-2
+
+
 @pytest.mark.parametrize("N,L,B,H,nch,gated", [(256, 128, 9, 2, 1, True), (1024, 1024, 3, 2, 1, False), (4096, 2048, 5, 2, 2, True),
                                                (16384, 8192, 3, 1, 1, False), (32768, 16384, 3, 2, 2, True)])
 @pytest.mark.parametrize("dt", [0, 1])
