@@ -33,19 +33,21 @@ if _os.environ.get("FFC_BIG_1LEVEL", "0") == "1":
 # 128-point factor runs as 4 passes of the 32-point outer kernel (ops.outer with n0 = 128 -> ffc_outer_pass_r), each reading
 # the quarter-length rows and writing its 32 of the 128 rows per head -- one HBM round trip instead of two
 # (reference: the 128-point butterfly, butterfly_padded_cuda_bf16.cu:302-487, conv.py:511-551).  FFC_BIG_ONE128=0 disables it.
-ONE128 = {4194304: ((128,), 32768)} if _os.environ.get("FFC_BIG_ONE128", "1") != "0" else {}
+# The same with R = 2 for fft 2097152 when L <= N / 2: 64 x 32768 (single-pass inner kernel, which also has the saved-spectra
+# backward) instead of 32 x the 2-pass fft 65536.
+ONE128 = {4194304: ((128,), 32768), 2097152: ((64,), 32768)} if _os.environ.get("FFC_BIG_ONE128", "1") != "0" else {}
 
 
 def choose(N, Lmax, ops=None):
     """(outer factors, fused inner size) for fft size N when no long-side row is longer than Lmax"""
-    if N in ONE128 and Lmax <= N // 4 and getattr(ops, "HAS_128", False):
+    if N in ONE128 and Lmax <= N // (ONE128[N][0][0] // 32) and getattr(ops, "HAS_128", False):
         return ONE128[N]
     return BIG_FACTORS[N]
 
 
 def level_scale(n0):
     """forward scale of one level ~ 1/sqrt(N0) (keeps the spectrum RMS near the input RMS)"""
-    return 0.25 if n0 == 16 else 0.125 if n0 == 32 else 0.0625
+    return {16: 0.25, 32: 0.125, 64: 0.125, 128: 0.0625}[n0]
 
 
 def inner_sfwd(M):

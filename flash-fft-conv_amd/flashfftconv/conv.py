@@ -147,9 +147,10 @@ class _TorchOps:
     HAS_128 = True      # factor 128 as 4 passes of the 32-point kernel (bigfft.choose)
 
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
-        if n0 == 128:
-            pr = self._plan(131072)      # the 4-pass plan: its per-pass outer-digit tables are the matrices of the passes
-            for c in range(4):
+        if n0 in (64, 128):
+            R = n0 // 32
+            pr = self._plan(32768 * R)      # the R-pass plan: its per-pass outer-digit tables are the matrices of the passes
+            for c in range(R):
                 _lib.check(_lib.lib().ffc_outer_pass_r(pr.handle, c, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
                                                        npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_r")
             return

@@ -118,9 +118,9 @@ class SimOps:
     HAS_128 = True
 
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
-        if n0 == 128:        # factor 128 = 4 passes of the 32-point kernel (ffc_outer_pass_r)
-            for c in range(4):
-                rc = lib().ffcsim_big_outer_r(32, 4, c, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,
+        if n0 in (64, 128):        # factor R * 32 = R passes of the 32-point kernel (ffc_outer_pass_r)
+            for c in range(n0 // 32):
+                rc = lib().ffcsim_big_outer_r(32, n0 // 32, c, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,
                                               ctypes.c_float(scale))
                 assert rc == 0, rc
             return

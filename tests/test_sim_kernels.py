@@ -167,12 +167,12 @@ def test_big_sizes_through_outer_levels(N, L, B, gated):
     assert rel(dk, dkref) < 1.5e-2
 
 
-@pytest.mark.parametrize("L,B,gated", [(131072, 2, False), (100004, 1, True)])
-def test_one_level_of_128(L, B, gated):
+@pytest.mark.parametrize("L,B,gated,f", [(131072, 2, False, 128), (100004, 1, True, 128), (131072, 1, True, 64), (77776, 3, False, 64)])
+def test_one_level_of_128(L, B, gated, f):
     """the factor-128 level (4 passes of the 32-point outer kernel, ffc_outer_pass_r: how fft 4194304 = 128 x 32768 runs when
     L <= N / 4) on a size the simulator finishes: fft 524288 = 128 x 4096, L <= N / 4, forward (gated, ragged, odd batch) and dk."""
     from flashfftconv import bigfft as BG
-    N, fac = 524288, ((128,), 4096)
+    N, fac = f * 4096, ((f,), 4096)          # L <= N / (f / 32)
     rng = np.random.default_rng(L)
     dt, H, M = 0, 1, 4096
     ops = S.SimOps()
@@ -181,7 +181,7 @@ def test_one_level_of_128(L, B, gated):
     ub, g1b, g2b, db = (S.to_bits(x, dt) for x in (u, g1, g2, d))
     kf = BG.kernel_fft(ops, dt, N, k, H, L, fac)
     x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None, fac)
-    assert x.shape == (2 * ((B + 1) // 2), H * 128, M)
+    assert x.shape == (2 * ((B + 1) // 2), H * f, M)
     y = ops.conv(dt, M, x, kf, False)
     out = np.zeros_like(ub)
     BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None, None, fac)
