@@ -332,12 +332,12 @@ static inline int ffc_fail(const std::string& m) { ffc_set_error_(m.c_str()); re
     if (e_ != hipSuccess) return ffc_fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Dynamic-LDS limit of a kernel: the attribute is per device, so it is set once per (kernel, device) -- a process that drives
+// several GPUs (per-device plan cache in flashfftconv.conv.get_plan) would otherwise launch > 64 KB kernels on its second
+// device with the first device's setting only.
+int ffc_set_lds_once(const void* kernel, int bytes);      // ffc_hip.hip
 template <class K>
-static int ffc_set_lds(K kernel, int bytes) {
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return ffc_fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-  return 0;
-}
+static int ffc_set_lds(K kernel, int bytes) { return ffc_set_lds_once((const void*)kernel, bytes); }
 
 template <template <class, int> class FN, class... A>
 static int ffc_dispatch(int N, int dtype, A&&... args) {

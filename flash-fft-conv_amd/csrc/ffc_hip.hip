@@ -43,6 +43,21 @@ __global__ void selftest_kernel(const uint32_t* in, uint32_t* out) {
 using namespace ffc;
 
 static thread_local std::string g_err;
+#include <map>
+#include <mutex>
+int ffc_set_lds_once(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> largest size set
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return ffc_fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+  done[{kernel, dev}] = bytes;
+  return 0;
+}
 #define fail ffc_fail
 
 // Test support: leave every CU's LDS and register files full of NaN patterns, so that a kernel which reads LDS or

@@ -9,7 +9,7 @@ __global__ __launch_bounds__(GeoBig<N0>::WGW * 64, 2) void big_kernel(BigArgs a)
 
 template <int N0, int DT, bool FWD>
 static int launch_big(const BigArgs& a, hipStream_t st) {
-  static int rc = ffc_set_lds(big_kernel<N0, DT, FWD>, GeoBig<N0>::LDS_BYTES);
+  int rc = ffc_set_lds(big_kernel<N0, DT, FWD>, GeoBig<N0>::LDS_BYTES);
   if (rc) return rc;
   const int64_t nwg = (int64_t)a.npair * a.Hin * (a.Mi / GeoBig<N0>::Mi);
   if (nwg <= 0 || nwg > 2147483647LL) return ffc_fail("outer pass: bad grid");

@@ -52,11 +52,11 @@ struct BwdLaunch {
       if constexpr (GEO::N == 32768) {
         const dim3 grid(ngrid), block(GEO::WGW * 64);
         if (16 * GEO::Mi >= d.c.L) {
-          static int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
         } else {
-          static int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
         }
@@ -71,7 +71,7 @@ struct BwdLaunch {
     if constexpr (!GEO::OUTER) {
       using BD = Body<DevB, GEO, DT>;
       const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
-      static int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
+      int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
       if (rc) return rc;
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       const int cap = (d.c.persist > 0 && d.c.persist < (1 << 29)) ? 2 * d.c.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
@@ -80,12 +80,12 @@ struct BwdLaunch {
       const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
       if (half) {
         {
-          static int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
         }
       } else {
-        static int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+        int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
         if (rc) return rc;
         hipLaunchKernelGGL((bwd_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
       }
@@ -121,7 +121,7 @@ extern "C" int ffc_conv_bwd(const ffc_plan* p, const void* dout, const void* u, 
   return ffc_conv_bwd_gated(p, dout, u, kf, pregate, postgate, du, dpre, nullptr, ws, B, H, L, stream);
 }
 // + dpost = dout * conv(u*pregate, k) (nullable).  Fused sizes >= 4096 produce it inside the same launch (one extra
-// inverse transform per pair); the single-tile sizes (N <= 1024) run the forward kernel with dout as the output gate.
+// inverse transform per pair); the single-tile sizes (fft <= 2048: the 1024 kernel and its 2-pass form) run the forward kernel with dout as the output gate.
 // Batch strides in elements (0 = contiguous H * L): every tensor may be a channel slice of a wider (B, C, L) tensor.
 extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                                     void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,

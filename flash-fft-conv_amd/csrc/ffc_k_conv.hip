@@ -73,11 +73,11 @@ struct ConvLaunch {
       if constexpr (GEO::N == 32768) {
         if (a.zsave) {
           if (16 * GEO::Mi >= a.L) {
-            static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
+            int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
             if (rc) return rc;
             hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, true, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
           } else {
-            static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
+            int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
             if (rc) return rc;
             hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
           }
@@ -85,11 +85,11 @@ struct ConvLaunch {
           return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel (spectrum-saving) launch: ") + hipGetErrorString(e));
         }
         if (16 * GEO::Mi >= a.L) {
-          static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
         } else {
-          static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
         }
@@ -97,7 +97,7 @@ struct ConvLaunch {
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else if constexpr (GEO::N == 1024) {
         constexpr int lds = GEO::LDS_BYTES + 2 * BD::IPASS_BYTES;
-        static int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
+        int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
         if (rc) return rc;
         const int cap = (a.persist > 0 && a.persist < (1 << 29)) ? 2 * a.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
         hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
@@ -112,11 +112,11 @@ struct ConvLaunch {
     if (a.zsave) {
       if constexpr (GEO::OUTER) {
         if ((GEO::N1 / 2) * GEO::Mi >= a.L) {
-          static int rc = ffc_set_lds(conv_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(conv_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((conv_kernel<GEO, DT, true, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
         } else {
-          static int rc = ffc_set_lds(conv_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(conv_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((conv_kernel<GEO, DT, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
         }
@@ -128,11 +128,11 @@ struct ConvLaunch {
     }
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
     if (GEO::OUTER && (GEO::N1 / 2) * GEO::Mi >= a.L) {
-      static int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+      int rc = ffc_set_lds(conv_kernel<GEO, DT, true>, GEO::LDS_BYTES);
       if (rc) return rc;
       hipLaunchKernelGGL((conv_kernel<GEO, DT, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
     } else {
-      static int rc = ffc_set_lds(conv_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+      int rc = ffc_set_lds(conv_kernel<GEO, DT, false>, GEO::LDS_BYTES);
       if (rc) return rc;
       hipLaunchKernelGGL((conv_kernel<GEO, DT, false>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
     }
@@ -234,7 +234,7 @@ extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* k
   a.flags = p->env_flags;
   a.prof = prof;
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc);
-  static int rc = ffc_set_lds(conv_prof_kernel<GEO, DT_BF16>, GEO::LDS_BYTES);
+  int rc = ffc_set_lds(conv_prof_kernel<GEO, DT_BF16>, GEO::LDS_BYTES);
   if (rc) return rc;
   int hpad = (a.H + 7) & ~7;
   if (grid_out) *grid_out = hpad * a.nchunk;

@@ -11,7 +11,7 @@ struct DkLaunch {
   static int run(const DkArgs& a, hipStream_t st) {
     using BD = Body<DevB, GEO, DT>;
     const int lds = GEO::LDS_BYTES + ((!GEO::OUTER && a.R > 1) ? a.R * BD::IPASS_BYTES : 0);   // inner-only multi-pass tables
-    static int rc = ffc_set_lds(dkifft_kernel<GEO, DT>, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 2 * BD::IPASS_BYTES));
+    int rc = ffc_set_lds(dkifft_kernel<GEO, DT>, GEO::LDS_BYTES + (GEO::OUTER ? 0 : 2 * BD::IPASS_BYTES));
     if (rc) return rc;
     const int nunits = GEO::OUTER ? a.H : (a.H + GEO::G - 1) / GEO::G;
     hipLaunchKernelGGL((dkifft_kernel<GEO, DT>), dim3((nunits + GEO::UPW - 1) / GEO::UPW), dim3(GEO::WGW * 64), lds, st, a);

@@ -45,11 +45,11 @@ struct DkfLaunch {
       if constexpr (GEO::N == 32768) {
         const dim3 grid(ngrid), block(GEO::WGW * 64);
         if (16 * GEO::Mi >= d.c.L) {
-          static int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((dkf_rp_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
         } else {
-          static int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(dkf_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((dkf_rp_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
         }
@@ -64,7 +64,7 @@ struct DkfLaunch {
     if constexpr (!GEO::OUTER) {
       using BD = Body<DevB, GEO, DT>;        // inner-only multi-pass form (fft 2048): per-pass tables behind the plan tables
       const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
-      static int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
+      int rc = ffc_set_lds(dkf_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
       if (rc) return rc;
       if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
       hipLaunchKernelGGL((dkf_kernel_small<GEO, DT>), grid, block, lds, st, d);
@@ -72,12 +72,12 @@ struct DkfLaunch {
       const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
       if (half) {
         {
-          static int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
+          int rc = ffc_set_lds(dkf_kernel<GEO, DT, true>, GEO::LDS_BYTES);
           if (rc) return rc;
           hipLaunchKernelGGL((dkf_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
         }
       } else {
-        static int rc = ffc_set_lds(dkf_kernel<GEO, DT, false>, GEO::LDS_BYTES);
+        int rc = ffc_set_lds(dkf_kernel<GEO, DT, false>, GEO::LDS_BYTES);
         if (rc) return rc;
         hipLaunchKernelGGL((dkf_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
       }

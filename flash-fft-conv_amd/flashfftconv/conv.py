@@ -17,10 +17,11 @@ from . import bigfft as _big
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
-# fft sizes that run as R passes of the fused 32768 kernel (csrc/ffc_body.h struct Pass) instead of an HBM-level outer pass
-# around a smaller fused kernel (flashfftconv/bigfft.py).  The library has the kernels for 65536 (R = 2) and 131072 (R = 4);
-# measured (profiles/r02_multipass.txt) the 2-pass form is 1.4x faster than the HBM level at fft 65536, the 4-pass form
-# re-reads too much and loses to it at fft 131072, so only 65536 is routed here (FFC_MULTIPASS="65536,131072" / "" for A/B)
+# fft sizes that run as R passes of a fused kernel (csrc/ffc_body.h struct Pass) instead of an HBM-level outer pass around a
+# smaller fused kernel (flashfftconv/bigfft.py): 2048 (2 passes of the 1024 kernel), 65536 and 131072 (2 / 4 passes of the
+# 32768 kernel) -- all three by default.  Measured: 65536 1.4x faster than the HBM level (profiles/r02_multipass.txt); 131072
+# forward 1.12x, and with the spectra kept for the backward pass (round 3) its fwd+bwd 15.8 -> 12.8 ms (profiles/r03_spectrum.txt)
+# where the HBM-level form measured 16.5.  FFC_MULTIPASS="2048,65536" etc. selects other routings for A/B runs.
 import os as _os
 MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "2048,65536,131072").split(",") if x.strip())
 # fft size 2048 has no 16/32-digit factorisation of its own.  By default it runs as 2 passes of the 1024 kernel
