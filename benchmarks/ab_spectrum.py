@@ -12,7 +12,7 @@ def ev(fn, it=20):
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
-cases = [(65536, 16, 768, 32768, False), (131072, 16, 768, 65536, False), (65536, 8, 256, 32768, True), (32768, 16, 768, 16384, False), (32768, 16, 768, 32768, False), (16384, 8, 1024, 8192, True), (8192, 16, 768, 4096, False), (4096, 16, 768, 2048, False),
+cases = ([tuple(int(x) for x in a.split(',')[:4]) + (a.endswith('g'),) for a in sys.argv[1:]] if len(sys.argv) > 1 else None) or [(65536, 16, 768, 32768, False), (131072, 16, 768, 65536, False), (65536, 8, 256, 32768, True), (32768, 16, 768, 16384, False), (32768, 16, 768, 32768, False), (16384, 8, 1024, 8192, True), (8192, 16, 768, 4096, False), (4096, 16, 768, 2048, False),
          (16384, 5, 111, 8000, True), (32768, 3, 24, 16380, True)]
 for (N, B, H, L, gated) in cases:
     torch.manual_seed(0)

@@ -116,13 +116,16 @@ def ev_time(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+FORMS = ("torch", "dropin", "fused")
+
+
 def run(name, dtype=torch.bfloat16):
     d_model, n_layer, L, B = CONFIGS[name][:4]
     inner = CONFIGS[name][4] if len(CONFIGS[name]) > 4 else 4
     dtype = CONFIGS[name][5] if len(CONFIGS[name]) > 5 else dtype
     ids = torch.randint(0, 12, (B, L), device="cuda")
     outs = {}
-    for form in ("torch", "dropin", "fused"):
+    for form in FORMS:
         torch.manual_seed(0)
         model = Backbone(d_model, n_layer, L, form, dtype, inner=inner).cuda().to(dtype).eval()
         for m in model.modules():                    # the long filter stays fp32 (the reference passes fp32 k to FlashFFTConv)
@@ -132,7 +135,7 @@ def run(name, dtype=torch.bfloat16):
             y = model(ids)
             ms = ev_time(lambda: model(ids), 3 if L > 200000 else 10)
         outs[form] = y.float()
-        diff = ((outs[form] - outs["torch"]).norm() / outs["torch"].norm()).item()
+        diff = ((outs[form] - outs["torch"]).norm() / outs["torch"].norm()).item() if "torch" in outs else float("nan")
         print(json.dumps({"model": f"hyenadna-{name}", "d_model": d_model, "n_layer": n_layer, "seqlen": L, "batch": B,
                           "fft_size": fft_size_for(L), "form": form, "dtype": str(dtype).split(".")[-1], "ms": round(ms, 3),
                           "tokens_per_ms": round(B * L / ms, 1), "seqs_per_s": round(B / (ms * 1e-3), 2),
@@ -142,5 +145,9 @@ def run(name, dtype=torch.bfloat16):
 
 
 if __name__ == "__main__":
-    for n in (sys.argv[1:] or ["tiny-16k", "small-32k", "medium-160k", "large-1m"]):
+    args = sys.argv[1:]
+    if args and args[0].startswith("--forms="):      # e.g. --forms=dropin under rocprofv3 --stats: one form's kernels only
+        FORMS = tuple(args[0][8:].split(","))
+        args = args[1:]
+    for n in (args or ["tiny-16k", "small-32k", "medium-160k", "large-1m"]):
         run(n)

@@ -59,6 +59,9 @@ struct ConvArgs {
   // with zsave, optional: the output BEFORE the postgate multiply, contiguous (B,H,L) dtype (the gated backward's
   // dpostgate = dout * this, which then needs no inverse transform of the saved spectrum)
   void* yraw;
+  // > 0: low-pass k_f whose non-zero bins all have k3 < sparse or k3 >= 32 - sparse (sparse <= 4): the kernel skips the
+  // all-zero spectrum rows (ffc_conv_fwd_sparse; 32-point inner digits only)
+  int sparse;
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
 };
 
@@ -240,6 +243,7 @@ struct Body {
     copy_tab(tab + t.twin, GEO::L_TW, 8192);
     if constexpr (GEO::N3 != GEO::N2) copy_tab(tab + t.mat[2], GEO::L_F3, 6144);
     if constexpr (GEO::TW2_SEP) copy_tab(tab + t.twin2, GEO::L_TW2, 8192);
+    if constexpr (GEO::HAS_SP) copy_tab(tab + t.mat_sp, GEO::L_FS, 3072);
     B::barrier();
   }
   static FFC_FN void lds_mat(Mat& m, int off) {
@@ -1133,6 +1137,93 @@ struct Body {
     k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
     cmul(re, im, k);
   }
+  // ---- frequency-sparse phase B (SP): only the spectrum rows k3 = 0..3 (accumulator registers 0..3 of lane half 0) and
+  // 28..31 (registers 12..15 of lane half 1) can be non-zero, because k_f is zero everywhere else.  Every lane works on its
+  // registers {0..3, 12..15} (the unused half of the set multiplies zeros of k_f), the other eight are never touched again.
+  struct KfRegsSp { U4 v[2]; };      // rows rq = 0 and rq = 3 of KfRegs
+  static FFC_FN void load_kf_sp(const ConvArgs& a, int h, int tau, KfRegsSp& k) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 c = lane & 31, hi = lane >> 5;
+    const uint8_t* kfh = (const uint8_t*)a.kf + (int64_t)h * (GEO::NT * 1024 * 4);
+    k.v[0] = B::g_r128(kfh, ((hi + (tau * 8 + 0)) * 32 + c));
+    k.v[1] = B::g_r128(kfh, ((hi + (tau * 8 + 6)) * 32 + c));
+  }
+  static FFC_FN void kf_mul_sp(const ConvArgs& a, const KfRegsSp& kf, A16& re, A16& im) {
+    const float sg = a.conj_kf ? -1.0f : 1.0f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      u32 wv[4] = {kf.v[s2].x, kf.v[s2].y, kf.v[s2].z, kf.v[s2].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 12 * s2 + q;
+        f32 kr = B::template unpack_lo<DT>(wv[q]), ki = B::template unpack_hi<DT>(wv[q]) * sg;
+        f32 x = re[r], y = im[r];
+        re[r] = x * kr - y * ki;
+        im[r] = x * ki + y * kr;
+      }
+    }
+  }
+  // the one K-step of the sparse inverse stage b: slots e < 4 = this lane half's four live rows, slots e >= 4 = zero
+  static FFC_FN void to_op_sp(const A16& re, const A16& im, Op& o) {
+    const pred up = (B::opaque(B::lane()) >> 5) >= 1;
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      o.r[0][d] = B::sel(up, B::template pack<DT>(re[12 + 2 * d], re[13 + 2 * d]), B::template pack<DT>(re[2 * d], re[2 * d + 1]));
+      o.i[0][d] = B::sel(up, B::template pack<DT>(im[12 + 2 * d], im[13 + 2 * d]), B::template pack<DT>(im[2 * d], im[2 * d + 1]));
+      o.r[0][2 + d] = B::uconst(0); o.i[0][2 + d] = B::uconst(0);
+      o.r[1][d] = B::uconst(0); o.i[1][d] = B::uconst(0); o.r[1][2 + d] = B::uconst(0); o.i[1][2 + d] = B::uconst(0);
+    }
+  }
+  static FFC_FN void lds_mat_sp(Mat& m) {
+    const i32 lane = B::lane();
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      U4 v = B::lds_r128(lane * 16 + (GEO::L_FS + q * 1024));
+      m.w[0][q] = B::w4(v.x, v.y, v.z, v.w);
+      m.w[1][q] = B::w4(B::uconst(0), B::uconst(0), B::uconst(0), B::uconst(0));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) B::pin(m.w[0][q]);
+  }
+  // two tiles of the pair in lock-step, sparse spectrum (the dense form is inner_tile2)
+  static FFC_FN void inner_tile2_sp(const ConvArgs& a, int h, int tauA, const InnerRegs& R, const Mat& Fs, Unit un) {
+    static_assert(GEO::HAS_SP, "sparse phase B: 32-point inner digits");
+    const int tauB = tauA + 1;
+    KfRegsSp kfA, kfB;
+    load_kf_sp(a, h, tauA, kfA);
+    load_kf_sp(a, h, tauB, kfB);
+    Op opA, opB;
+    load_tile_op(tauA, opA, un, R);
+    load_tile_op(tauB, opB, un, R);
+    A16 reA, imA, reB, imB;
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, true>(reA, imA, opA, R.F2);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, true>(reB, imB, opB, R.F2);
+    cmul(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<false, false>(reA, imA, opA, R.F2);
+    cmul(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<false, false>(reB, imB, opB, R.F2);
+    // (x) k_f on the live rows, inverse stage b with ONE K-step
+    kf_mul_sp(a, kfA, reA, imA); to_op_sp(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<true, true>(reA, imA, opA, Fs, 1);
+    kf_mul_sp(a, kfB, reB, imB); to_op_sp(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<true, true>(reB, imB, opB, Fs, 1);
+    cmul_conj(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm<true, true>(reA, imA, opA, R.F2);
+    cmul_conj(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm<true, true>(reB, imB, opB, R.F2);
+    oi_twiddle<false>(a.s_inv, tauA, reA, imA);
+    tile_store(tauA, R, reA, imA);
+    oi_twiddle<false>(a.s_inv, tauB, reB, imB);
+    tile_store(tauB, R, reB, imB);
+  }
   template <bool RP = false>
   static FFC_FN void oi_twiddle(float s_inv, int tau, A16& re, A16& im, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
@@ -1297,7 +1388,7 @@ struct Body {
     if constexpr (GEO::NW > 1) B::barrier();
     else B::lds_fence();
   }
-  template <bool HALF, bool PROF = false, bool RP = false, bool SZ = false>
+  template <bool HALF, bool PROF = false, bool RP = false, bool SZ = false, bool SP = false>
   static FFC_FN void outer_jobs(const ConvArgs& a, int h, int p0, int p1, int u, Unit un, int wg_linear = 0) {
     constexpr int NC = HALF ? NCH / 2 : NCH;
     // HALF: the next pair's rows (32 VGPRs) are prefetched behind the last k_f load of phase B, so they
@@ -1311,7 +1402,7 @@ struct Body {
 #if defined(FFC_NO_CROSS)
     constexpr bool CROSS = false;
 #else
-    constexpr bool CROSS = !RP && !PROF && !B::LEAN_OUTER && GEO::N3 == GEO::N2 && GEO::NW > 1 && GEO::UPW >= 2;
+    constexpr bool CROSS = !SP && !RP && !PROF && !B::LEAN_OUTER && GEO::N3 == GEO::N2 && GEO::NW > 1 && GEO::UPW >= 2;
 #endif
     // (a split prefetch for the full-length kernels -- first half of the next pair's rows early, second half at the top of
     // the iteration -- was measured: the 32768 kernel then needs 256 VGPRs + 16 spilled and runs the same, 8192 gains 2-4 %;
@@ -1371,7 +1462,12 @@ struct Body {
 #if defined(FFC_KO) && (FFC_KO & 16)
         if (a.L < 0)
 #endif
-        if constexpr (GEO::N3 == GEO::N2) {
+        if constexpr (SP) {
+          Mat Fs;
+          lds_mat_sp(Fs);
+#pragma unroll 1
+          for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2_sp(a, hk, un.wq * GEO::TPW + tt, R, Fs, un);
+        } else if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2)
             inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
@@ -1421,13 +1517,13 @@ struct Body {
   // ------------------------------------------------------------------ workgroup entry: conv
   // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
   // HALF is chosen by the launcher: 32-point outer digit and L <= N/2
-  template <bool HALF = false, bool SZ = false>
+  template <bool HALF = false, bool SZ = false, bool SP = false>
   static FFC_FN void conv(const ConvArgs& a, int h, int chunk) {
     setup_tables(a.tab, a.t);
-    conv_job<HALF, false, SZ>(a, h, chunk);
+    conv_job<HALF, false, SZ, SP>(a, h, chunk);
   }
   // one (head, chunk) job; the tables are already in LDS.  RP: all passes of a multi-pass size
-  template <bool HALF = false, bool RP = false, bool SZ = false>
+  template <bool HALF = false, bool RP = false, bool SZ = false, bool SP = false>
   static FFC_FN void conv_job(const ConvArgs& a, int h, int chunk) {
     const int wv = B::wave();
     Unit un;
@@ -1438,7 +1534,7 @@ struct Body {
     int p1 = p0 + a.ppc;
     if (p1 > a.npair) p1 = a.npair;
     if constexpr (GEO::OUTER) {
-      outer_jobs<HALF, false, RP, SZ>(a, h, p0, p1, u, un);
+      outer_jobs<HALF, false, RP, SZ, SP>(a, h, p0, p1, u, un);
     } else {
       // one tile of G pairs per wave
       const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;

@@ -6,7 +6,7 @@ using namespace ffc;
 #ifndef FFC_SMALL_WAVES
 #define FFC_SMALL_WAVES 2
 #endif
-template <class GEO, int DT, bool HALF, bool SZ = false>
+template <class GEO, int DT, bool HALF, bool SZ = false, bool SP = false>
 __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) void conv_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
 #if defined(FFC_SETPRIO)
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) vo
     int h, chunk;
     if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
     stagger_start(a.flags);
-    BD::template conv<HALF, SZ>(a, h, chunk);
+    BD::template conv<HALF, SZ, SP>(a, h, chunk);
   }
 }
 
@@ -109,6 +109,23 @@ struct ConvLaunch {
     }
     if (GEO::OUTER && GEO::NW == 1 && grid > a.persist) grid = a.persist;      // persistent: one workgroup per CU
     if (!GEO::OUTER && a.persist > 0 && a.persist < (1 << 29) && grid > 2 * a.persist) grid = 2 * a.persist;      // persistent: two per CU
+    if (a.sparse) {
+      if constexpr (GEO::HAS_SP) {
+        if ((GEO::N1 / 2) * GEO::Mi >= a.L) {
+          int rc = ffc_set_lds(conv_kernel<GEO, DT, true, false, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_kernel<GEO, DT, true, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        } else {
+          int rc = ffc_set_lds(conv_kernel<GEO, DT, false, false, true>, GEO::LDS_BYTES);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_kernel<GEO, DT, false, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        }
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel (frequency-sparse) launch: ") + hipGetErrorString(e));
+      } else {
+        return ffc_fail("frequency-sparse kernel: fft 16384 / 32768 only");
+      }
+    }
     if (a.zsave) {
       if constexpr (GEO::OUTER) {
         if ((GEO::N1 / 2) * GEO::Mi >= a.L) {
@@ -153,7 +170,7 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
   return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;        // (hp.N = the plan's fft size, R passes x the kernel size)
 }
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
-                         void* y, void* zsave, void* yraw, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
+                         void* y, void* zsave, void* yraw, int sparse, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                          int64_t sb_post, int64_t sb_y, void* stream) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
@@ -169,6 +186,9 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_y;
   a.conj_kf = conj_kf;
   a.zsave = zsave; a.yraw = zsave ? yraw : nullptr;
+  a.sparse = sparse;
+  if (sparse && (sparse < 0 || sparse > 4 || zsave || p->hp.R > 1 || p->hp.N2 != 32 || p->hp.N3 != 32 || p->hp.N1 <= 1))
+    return ffc_fail("frequency-sparse forward: fft 16384 / 32768, 1 <= rows <= 4, no spectrum buffer");
   if (zsave && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zsave & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   a.s_inv = (float)p->hp.s_inv; a.s_fwd = (float)p->hp.s_fwd;
   a.flags = p->env_flags;
@@ -185,7 +205,7 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
 extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                                     void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                                     int64_t sb_post, int64_t sb_y, void* stream) {
-  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, nullptr, B, H, L, conj_kf, sb_u, sb_pre, sb_post, sb_y, stream);
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, nullptr, 0, B, H, L, conj_kf, sb_u, sb_pre, sb_post, sb_y, stream);
 }
 // forward that also stores every pair's spectrum FFT(u * pregate) in `zsave` (ffc_spectrum_bytes) for ffc_conv_bwd_z and,
 // when y_raw is given (16-byte aligned, contiguous (B,H,L)), the output before the postgate multiply
@@ -194,7 +214,17 @@ extern "C" int ffc_conv_fwd_z(const ffc_plan* p, const void* u, const void* kf, 
                               int64_t sb_y, void* stream) {
   if (!zsave) return ffc_fail("null spectrum buffer");
   if (y_raw && ((uintptr_t)y_raw & 15)) return ffc_fail("y_raw must be 16-byte aligned");
-  return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, y_raw, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, y_raw, 0, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
+}
+
+// Forward / input-gradient pass with a LOW-PASS k_f: every non-zero bin f has k3 = f / (N1 N2) < rows or >= 32 - rows
+// (rows <= 4), i.e. |f| < rows * N / 32 (FrequencySparseFFTConv with N_partial <= N / 4).  Same result as ffc_conv_fwd on the
+// same (masked) k_f; the kernel skips the all-zero spectrum rows: half of the k_f loads and of the k_f product, and one of
+// the two K-steps of the first inverse stage (reference: the truncated kernels, monarch_cuda/monarch_fwd_complex.h:462-528).
+extern "C" int ffc_conv_fwd_sparse(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
+                                   void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int rows, void* stream) {
+  if (rows < 1) return ffc_fail("frequency-sparse forward: rows must be >= 1");
+  return conv_fwd_impl(p, u, kf, pregate, postgate, y, nullptr, nullptr, rows, B, H, L, conj_kf, 0, 0, 0, 0, stream);
 }
 
 extern "C" int ffc_conv_fwd(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,

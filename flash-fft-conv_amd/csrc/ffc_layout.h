@@ -56,7 +56,9 @@ struct Geo {
   static constexpr int L_TW2 = L_TW + 8192;
   static constexpr bool TW2_SEP = (N3 != N2) || !OUTER;   // separate inverse inner-twiddle table
   static constexpr int L_BASE = L_TW2 + (TW2_SEP ? 8192 : 0);
-  static constexpr int LDS_BYTES = L_BASE;   // outer twiddles are generated on the fly (no tables)
+  static constexpr bool HAS_SP = OUTER && N2 == 32 && N3 == 32;    // frequency-sparse kernel variant (PlanTabs::mat_sp)
+  static constexpr int L_FS = L_BASE;
+  static constexpr int LDS_BYTES = L_BASE + (HAS_SP ? 3072 : 0);   // outer twiddles are generated on the fly (no tables)
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(N2 == 16 || N2 == 32, "");
   static_assert(N3 == 16 || N3 == 32, "");

@@ -137,6 +137,29 @@ void fill_mat(uint8_t* dst, int Nd, int dtype) {
         }
 }
 
+// K-step-0 operand table of the 32-point DFT for the frequency-sparse inverse stage (PlanTabs::mat_sp): slots e < 4 of lane
+// half hi hold the contraction row k3 = e (hi = 0) / 28 + e (hi = 1), slots e >= 4 carry zero data.  [q = which][lane][d]
+void fill_mat_sparse(uint8_t* dst, int dtype) {
+  uint32_t* w = (uint32_t*)dst;
+  for (int which = 0; which < 3; which++)
+    for (int lane = 0; lane < 64; lane++)
+      for (int d = 0; d < 4; d++) {
+        uint32_t word = 0;
+        for (int half = 0; half < 2; half++) {
+          int e = 2 * d + half;
+          int out = lane & 31, con = (lane >> 5) ? 28 + e : e;
+          double re = 0, im = 0;
+          if (e < 4) {
+            double ang = -2.0 * kPi * (double)((out * con) % 32) / 32.0;
+            re = cos(ang); im = sin(ang);
+          }
+          double v = which == 0 ? re : (which == 1 ? im : -im);
+          word |= (uint32_t)to_dt(v, dtype) << (16 * half);
+        }
+        w[(which * 64 + lane) * 4 + d] = word;
+      }
+}
+
 // Outer-digit operand table of pass k0 of an R-pass size (Nd = 32): the Nd-point DFT times the pass factor
 // W_{R Nd}^{n1 k0} on the INPUT index n1.  Same [out][contraction] operand layout as fill_mat.  Forward (phase A):
 // out = k1, contraction = n1: F[k1][n1] = W_Nd^{n1 k1} W_{R Nd}^{n1 k0}.  Inverse (phase C, used with the kernels' CONJ
@@ -213,6 +236,8 @@ void build(HostPlan* p) {
     cis((double)(n3 * k2), GEO::Mi, GEO::OUTER ? 1.0 : p->s_inv, re, im);
   });
   for (int k0 = 0; k0 < 4; k0++) t.ipass[k0] = 0;
+  t.mat_sp = bl.alloc(3 * 64 * 16);
+  fill_mat_sparse(p->blob.data() + t.mat_sp, p->dtype);
   if (!GEO::OUTER && p->R > 1) {
     // inner-only multi-pass form: with m = N3 n2 + n3 the pass factor W_N^{m k0} = W_{N/N3}^{n2 k0} W_N^{n3 k0}; its n2 part
     // multiplies the stage-a matrix (contraction index) and, conjugated by the kernels' CONJ flag, the last inverse matrix

@@ -15,6 +15,9 @@ struct PlanTabs {      // byte offsets into the plan blob
   int matk[4][2];
   // inner-only multi-pass sizes (fft 2048 = 2 passes of the 32 x 32 kernel): per pass [Fa | Finv | tw | tw2] (28672 bytes)
   int ipass[4];
+  // frequency-sparse kernels (32-point inner digits): K-step-0 operand table of the 32-point DFT whose contraction slots hold
+  // k3 = 0..3 (lane half 0) and 28..31 (lane half 1) -- the only non-zero spectrum rows of a low-pass k_f (ffc_conv_fwd_sparse)
+  int mat_sp;
   int total;
 };
 

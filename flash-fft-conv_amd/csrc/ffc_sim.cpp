@@ -322,6 +322,13 @@ static void sim_conv_t(const ConvArgs& a) {
         }
       }
       run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+        if constexpr (GEO::HAS_SP) {      // frequency-sparse variant (ffc_conv_fwd_sparse)
+          if (a.sparse) {
+            if ((GEO::N1 / 2) * GEO::Mi >= a.L) Body<SimB, GEO, DT>::template conv<true, false, true>(a, h, c);
+            else Body<SimB, GEO, DT>::template conv<false, false, true>(a, h, c);
+            return;
+          }
+        }
         if constexpr (GEO::OUTER) {       // the launcher's HALF variant
           if ((GEO::N1 / 2) * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
         }
@@ -461,6 +468,8 @@ int ffcsim_plan_info(int N, int dtype, int* nt, double* s_fwd, double* s_k, int3
 }
 
 // Same contract as ffc_conv_fwd (include/flashfftconv_hip.h) but on host memory.
+static int g_sparse_rows = 0;
+void ffcsim_set_sparse(int rows) { g_sparse_rows = rows; }      // next ffcsim_conv_fwd calls run the frequency-sparse variant
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
                     void* y, int B, int H, int L, int conj_kf) {
   HostPlan p;
@@ -474,6 +483,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.nchunk = 1; a.ppc = a.npair; a.conj_kf = conj_kf; a.s_inv = (float)p.s_inv; a.s_fwd = (float)p.s_fwd;
   a.fast = (L % 8 == 0) && !g_force_slow;
   a.R = p.R;
+  a.sparse = g_sparse_rows;
   return dispatch<ConvRun>(N, dtype, a);
 }
 

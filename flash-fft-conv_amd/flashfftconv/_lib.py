@@ -29,6 +29,7 @@ def lib():
         L.ffc_kernel_fft.argtypes = [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]
         L.ffc_kf_pack.argtypes = [c_vp, c_vp, c_i64, c_vp, c_vp]
         L.ffc_conv_fwd.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_vp]
+        L.ffc_conv_fwd_sparse.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_vp]
         L.ffc_conv_fwd_strided.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_i64, c_i64, c_vp]
         L.ffc_conv_bwd_gated_strided.argtypes = [c_vp] * 10 + [c_i64] * 10 + [c_vp]
         L.ffc_spectrum_bytes.argtypes = [c_vp, c_i64, c_i64]; L.ffc_spectrum_bytes.restype = c_i64

@@ -101,6 +101,23 @@ def _conv(plan, u, kf, pregate, postgate, conj):
     return y
 
 
+def _sparse_rows(mod, plan):
+    """frequency-sparse module on a plan with the compute-skipping kernel (fft 16384 / 32768): number of kept spectrum rows
+    per side, k3 < rows or k3 >= 32 - rows covers every kept bin |f| < keep; 0 = dense kernel on the masked k_f."""
+    if mod._kf_keep is None or plan.seqlen not in (16384, 32768) or mod._folded:
+        return 0
+    rows = -(-int(mod._kf_keep) // (plan.seqlen // 32))
+    return rows if 1 <= rows <= 4 else 0
+
+
+def _conv_sparse(plan, u, kf, pregate, postgate, conj, rows):
+    B, H, L = u.shape
+    y = torch.empty_like(u)
+    _lib.check(_lib.lib().ffc_conv_fwd_sparse(plan.handle, _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
+                                              _lib.ptr(y), B, H, L, int(conj), rows, _lib.stream_ptr()), "ffc_conv_fwd_sparse")
+    return y
+
+
 def _spectrum_buffer(plan, B, H, device):
     """Buffer for the spectra FFT(u * pregate) that the forward pass keeps for the backward pass (ffc_conv_fwd_z / ffc_conv_bwd_z),
     or None: plan without that path (fft < 4096, multi-pass and HBM-level sizes), or no memory for it (the caller then takes the
@@ -358,14 +375,18 @@ class _FlashFFTConvFn(torch.autograd.Function):
             # of u): dpostgate = dout * that, instead of one more inverse transform of the spectrum.
             # module.save_spectrum = False (or FFC_SAVE_SPECTRUM=0) keeps the reference's recomputing backward.
             z = yraw = None
-            if mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
+            rows = _sparse_rows(mod, plan)      # low-pass k_f: the forward kernel that skips the all-zero spectrum rows
+            if rows:
+                out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
+            elif mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
                 z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device)
                 if z is not None and ctx.gated:
                     try:
                         yraw = torch.empty_like(u)
                     except torch.cuda.OutOfMemoryError:
                         z = None
-            out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
+            if not rows:
+                out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             # (z, yraw: saved tensors, released with the graph and kept by retain_graph like the others)
             if ctx.big:

@@ -58,6 +58,13 @@ int ffc_conv_fwd_strided(const ffc_plan* plan, const void* u, const void* kf, co
                          void* y, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                          int64_t sb_post, int64_t sb_y, void* stream);
 
+/* ffc_conv_fwd for a LOW-PASS k_f: every non-zero bin has k3 = f / (N1 N2) < rows or >= 32 - rows, rows <= 4, i.e.
+ * |f| < rows * N / 32 (FrequencySparseFFTConv with N_partial <= N / 4; the caller still passes the masked k_f).  Same result;
+ * the kernel skips the all-zero spectrum rows (half of the k_f loads and product, one of two K-steps of the first inverse stage).
+ * fft 16384 / 32768.  Reference: the truncated kernels, csrc/flashfftconv/monarch_cuda/monarch_fwd_complex.h:462-528. */
+int ffc_conv_fwd_sparse(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
+                        int64_t B, int64_t H, int64_t L, int conj_kf, int rows, void* stream);
+
 /* dk_f accumulation: dkf[h, :] (fp32 complex, internal order, scaled) = sum_b FFT(dout*postgate) * conj(FFT(u*pregate)).
  * ws: workspace of ffc_dkf_workspace_bytes() bytes (partial sums per chunk of batch pairs). */
 int64_t ffc_dkf_workspace_bytes(const ffc_plan* plan, int64_t B, int64_t H);

@@ -68,6 +68,13 @@ def make_kf_internal(k, N, dtype):
     return to_bits(out, dtype)
 
 
+def make_kf_from_spectrum(kf_natural, N, dtype):
+    """natural-order complex spectrum (H, N) -> internal-order k_f bits (H, NT*1024, 2)"""
+    nt, sf, sk, freq = plan_info(N, dtype)
+    kf = np.asarray(kf_natural)[:, freq] * sk
+    return to_bits(np.stack([kf.real, kf.imag], -1).astype(np.float32), dtype)
+
+
 def p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

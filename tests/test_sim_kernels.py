@@ -167,6 +167,36 @@ def test_big_sizes_through_outer_levels(N, L, B, gated):
     assert rel(dk, dkref) < 1.5e-2
 
 
+@pytest.mark.parametrize("N,L,rows", [(32768, 16384, 4), (32768, 32768, 2), (16384, 8192, 4), (16384, 5000, 1)])
+def test_frequency_sparse_kernel_skips_zero_rows(N, L, rows):
+    """ffc_conv_fwd_sparse (kernel variant SP): with a low-pass k_f (non-zero bins |f| < rows N / 32) the compute-skipping
+    kernel returns bit for bit what the dense kernel returns on the same masked k_f, forward and conj(k_f) pass."""
+    rng = np.random.default_rng(N + rows)
+    dt, B, H = 0, 3, 1
+    u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kfn = np.fft.fft(k.astype(np.float64), n=N)
+    f = np.arange(N)
+    kfn[:, (f >= rows * N // 32) & (f <= N - rows * N // 32)] = 0          # keep |f| < rows * N / 32
+    kf = S.make_kf_from_spectrum(kfn, N, dt)
+    ub = S.to_bits(u, dt)
+    for conj in (0, 1):
+        dense = S.sim_conv_fwd(N, dt, ub, kf, S.to_bits(g1, dt), S.to_bits(g2, dt), conj=conj)
+        S.lib().ffcsim_set_sparse(rows)
+        try:
+            sparse = S.sim_conv_fwd(N, dt, ub, kf, S.to_bits(g1, dt), S.to_bits(g2, dt), conj=conj)
+        finally:
+            S.lib().ffcsim_set_sparse(0)
+        assert np.array_equal(dense, sparse), f"conj={conj}: {int((dense != sparse).sum())} elements differ"
+    yref = np.fft.ifft(np.fft.fft(q(u, dt).astype(np.float64) * q(g1, dt), n=N) * kfn[None], n=N).real[..., :L] * q(g2, dt)
+    S.lib().ffcsim_set_sparse(rows)
+    try:
+        y = S.from_bits(S.sim_conv_fwd(N, dt, ub, kf, S.to_bits(g1, dt), S.to_bits(g2, dt)), dt)
+    finally:
+        S.lib().ffcsim_set_sparse(0)
+    assert rel(y, yref) < 1.5 * TOL[dt]
+
+
 @pytest.mark.parametrize("L,B,gated,f", [(131072, 2, False, 128), (100004, 1, True, 128), (131072, 1, True, 64), (77776, 3, False, 64)])
 def test_one_level_of_128(L, B, gated, f):
     """the factor-128 level (4 passes of the 32-point outer kernel, ffc_outer_pass_r: how fft 4194304 = 128 x 32768 runs when
