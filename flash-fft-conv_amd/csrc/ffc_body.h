@@ -26,6 +26,10 @@
 #ifndef FFC_FN
 #define FFC_FN inline __attribute__((always_inline))
 #endif
+// saved spectra (ConvArgs::zsave) written / read with streaming accesses (A/B: -DFFC_Z_STREAM=false keeps them cacheable)
+#ifndef FFC_Z_STREAM
+#define FFC_Z_STREAM true
+#endif
 
 namespace ffc {
 
@@ -1123,6 +1127,8 @@ struct Body {
   // Two tiles processed in lock-step: their chains are independent, so the MFMAs of one tile execute while
   // the twiddle / conversion VALU work of the other one issues (a single tile alternates MFMA-only and
   // VALU-only stretches and exposes the MFMA dependency latency each time).
+  // NOCONJ (compile time): the caller never asks for conj(k_f) (the spectrum-saving training forward): no sign multiply
+  template <bool NOCONJ = false>
   static FFC_FN void kf_mul(const ConvArgs& a, const KfRegs& kf, A16& re, A16& im) {
     CT16 k;
 #pragma unroll
@@ -1281,12 +1287,12 @@ struct Body {
     cmul(reB, imB, R.tw); to_op(reB, imB, opB);
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<false, false>(reB, imB, opB, R.F2);
-    if constexpr (SZ) { z_store(zs, tauA, reA, imA, true); z_store(zs, tauB, reB, imB, true); }     // spectrum kept for the backward pass
+    if constexpr (SZ) { z_store(zs, tauA, reA, imA, FFC_Z_STREAM); z_store(zs, tauB, reB, imB, FFC_Z_STREAM); }     // spectrum kept for the backward pass
     // (x) k_f, inverse stage b
-    kf_mul(a, kfA, reA, imA); to_op(reA, imA, opA);
+    kf_mul<SZ>(a, kfA, reA, imA); to_op(reA, imA, opA);
     reA = B::a16_zero(); imA = B::a16_zero();
     cmm<true, true>(reA, imA, opA, R.F2);
-    kf_mul(a, kfB, reB, imB); to_op(reB, imB, opB);
+    kf_mul<SZ>(a, kfB, reB, imB); to_op(reB, imB, opB);
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<true, true>(reB, imB, opB, R.F2);
     // inverse twiddle, inverse stage a
@@ -1327,7 +1333,7 @@ struct Body {
     cmul(reB, imB, R.tw); to_op(reB, imB, opB);
     reB = B::a16_zero(); imB = B::a16_zero();
     cmm<false, false>(reB, imB, opB, R.F2);
-    if constexpr (SZ) { z_store(zsA, tau, reA, imA, true); z_store(zsB, tau, reB, imB, true); }     // spectra kept for the backward pass
+    if constexpr (SZ) { z_store(zsA, tau, reA, imA, FFC_Z_STREAM); z_store(zsB, tau, reB, imB, FFC_Z_STREAM); }     // spectra kept for the backward pass
     // (x) k_f: unpacked once
     {
       CT16 k;
@@ -1340,7 +1346,7 @@ struct Body {
           k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
         }
       }
-      k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
+      if constexpr (!SZ) k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
       cmul(reA, imA, k); to_op(reA, imA, opA);
       reA = B::a16_zero(); imA = B::a16_zero();
       cmm<true, true>(reA, imA, opA, R.F2);

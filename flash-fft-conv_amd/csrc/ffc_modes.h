@@ -831,7 +831,7 @@ struct Modes : Body<B, GEO, DT> {
               for (int tt = 0; tt < GEO::TPW; tt++) {
                 const int tau = un.wq * GEO::TPW + tt;
                 typename BD::KfRegs zv, kf;
-                z_load(zp, tau, zv, true);
+                z_load(zp, tau, zv, FFC_Z_STREAM);
                 BD::load_kf(a, hk, tau, kf);
                 A16 re, im;
                 z_unpack(zv, re, im);
@@ -911,7 +911,7 @@ struct Modes : Body<B, GEO, DT> {
         FFC_BTICK(8)
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z);
+          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z && FFC_Z_STREAM);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
