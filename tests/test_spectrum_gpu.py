@@ -121,3 +121,35 @@ def test_no_spectrum_path_for_other_plans():
     uu = (torch.randn(2, 8, 512, device="cuda") * 0.1).bfloat16().requires_grad_(True); kk = torch.randn(8, 512, device="cuda").requires_grad_(True)
     conv(uu, kk).sum().backward()
     assert uu.grad is not None and kk.grad is not None
+
+
+@pytest.mark.gpu
+def test_training_step_captures_into_a_hip_graph():
+    """forward (spectra saved) + backward launch on torch's current stream with no host synchronisation and no allocation
+    outside torch's allocator, so the whole step can be captured and replayed as one HIP graph; replay == eager, bitwise"""
+    from flashfftconv import FlashFFTConv
+    N, B, H, L = 8192, 4, 16, 4096
+    torch.manual_seed(3)
+    u = torch.randn(B, H, L, device="cuda").bfloat16().requires_grad_(True)
+    k = torch.randn(H, L, device="cuda").requires_grad_(True)
+    dout = torch.randn(B, H, L, device="cuda").bfloat16()
+    mod = FlashFFTConv(N, dtype=torch.bfloat16).cuda()
+
+    def step():
+        u.grad = None; k.grad = None
+        mod(u, k).backward(dout)
+    step(); torch.cuda.synchronize()
+    du0, dk0 = u.grad.clone(), k.grad.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    u.grad = None; k.grad = None
+    with torch.cuda.graph(g):
+        mod(u, k).backward(dout)
+    u.grad.zero_(); k.grad.zero_()
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(u.grad, du0) and torch.equal(k.grad, dk0)
