@@ -298,21 +298,21 @@ def main():
              "t_ideal_hbm_us": t_hbm * 1e6, "t_ideal_mfma_executed_us": t_mfma * 1e6,
              "frac_hbm": hbm["frac"], "frac_executed": mf["frac"], "executed_TFLOPs": mf["achieved"],
              "frac_reference_basis": dense_row * rows / t / 1e12 / MFMA_PEAK_TFLOPS,
-             "basis": "achieved = algorithmic bytes (or executed MFMA flops) per launch / launch_ms; launch_ms = HIP events around a loop of "
-                      "launches of this kernel in this run (agrees with the rocprofv3 kernel-trace average, profiles/r03_kernel_stats.csv). "
-                      "An event after EVERY launch of the step sequence (launch_ms_event_bracketed_in_step) costs ~14 us per event: those "
-                      "four times add up to more than the measured step (kernel_sum_check)"}
+             "basis": "achieved = algorithmic bytes (or executed MFMA flops) per launch / launch_ms; launch_ms = HIP events after every "
+                      "launch of 20 back-to-back steps of this run (the conservative figure: each event costs the sequence ~14 us, so the "
+                      "four in-step times add up to MORE than the measured step, see kernel_sum_check); launch_ms_isolated_loop = events "
+                      "around a loop of launches of this kernel alone"}
         return r
 
     # the backward kernel on saved spectra executes one forward half + one inverse half per pair
     mf_bwd_saved = mf_bwd - 32 * (4 + 16)
     roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> on saved spectra (fused backward: du + fp32 dk_f)", mf_bwd_saved, dense_bwd, bwd_bytes,
-                    kt["bwd_fused_saved"], prof_traffic("r03_pmc_bwd_kernel.txt", "traffic"))
-    roof_bwd["launch_ms_event_bracketed_in_step"] = kt_step["bwd_fused_saved"] * 1e3
+                    kt_step["bwd_fused_saved"], prof_traffic("r03_pmc_bwd_kernel.txt", "traffic"))
+    roof_bwd["launch_ms_isolated_loop"] = kt["bwd_fused_saved"] * 1e3
     roof_bwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_read": npair * N * 4, "u_not_read_any_more": -B * H * L * 2}
     roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> (training forward, stores the spectra)", mf_fwd, dense_fwd, fwd_bytes,
-                    kt["conv_fwd_save"], prof_traffic("r03_pmc_conv_kernel.txt", "traffic"))
-    roof_fwd["launch_ms_event_bracketed_in_step"] = kt_step["conv_fwd_save"] * 1e3
+                    kt_step["conv_fwd_save"], prof_traffic("r03_pmc_conv_kernel.txt", "traffic"))
+    roof_fwd["launch_ms_isolated_loop"] = kt["conv_fwd_save"] * 1e3
     roof_fwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_write": npair * N * 4}
     for r in (roof_bwd, roof_fwd):      # bytes the kernel really has to move (incl. the spectra) vs the profiled traffic
         r["bytes_to_move"] = r["alg_bytes"] + sum(r["extra_bytes_not_in_alg_bytes"].values())
