@@ -23,3 +23,8 @@ jobs = (B + 1) // 2
 print(f"grid={grid.value} FLAGS={os.environ.get('FFC_FLAGS','0')} cycles per wave per pair (mean over waves), total {tot.mean().item()/jobs:.0f}")
 for i, n in enumerate(names[:7]):
     print(f"  {n:9s} {p[..., i].mean().item()/jobs:9.0f}  ({100*p[..., i].sum().item()/tot.sum().item():5.1f}%)   min {p[...,i].min().item()/jobs:8.0f} max {p[...,i].max().item()/jobs:8.0f}")
+# per wave index (SIMD = wave % 4): is the barrier skew systematic?
+print("per wave index, mean over workgroups (cycles per pair):")
+print("  wave " + " ".join(f"{n:>9s}" for n in names[:7]))
+for w in range(8):
+    print(f"  {w:4d} " + " ".join(f"{p[:, w, i].mean().item()/jobs:9.0f}" for i in range(7)))
