@@ -1421,6 +1421,22 @@ struct Body {
     if constexpr (PREFETCH) { if (p0 + u < p1) rows_load<NC>(a, h, p0 + u, un, X); }
     unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define FFC_TICK(k) if (PROF) { t1 = B::clock(); acc[k] += t1 - t0; t0 = t1; }
+    // Wave priority by progress.  The SIMD issues oldest-first: of its two resident waves (w and w + 4 of the workgroup) the
+    // first-dispatched one runs every phase at its single-wave speed, the other gets the issue slots left over (42 % of them
+    // in phase B) and then finishes alone -- at the single-wave rate, half the SIMD's (profiles/r03_wave_priority.txt: phase B
+    // 12.7 K cycles for waves 0-3, 20.1 K for waves 4-7, which the barrier waits for).  s_setprio steers that arbitration
+    // completely (same file: priority 1 on waves 4-7 mirrors the picture), so a wave lowers its priority as it advances through
+    // the slices between two barriers: the wave that is a slice behind outranks the wave that is ahead.  Slices are whole
+    // phases / phase-B iterations ON PURPOSE: half-iteration slices keep the two waves in the same stage of the same tile, where
+    // they compete for the same unit (MFMA against MFMA, twiddle VALU against twiddle VALU), and the kernel ran 12 % slower.
+    const bool second = B::wave() >= 4;
+    // (fft 4096, one wave per unit and no barriers between the waves: +3 % with priorities, so only where waves share a unit;
+    // same-box A/B: forward -2.1 % at fft 32768, -1.2 % at 16384, -2 % at 8192; -DFFC_NO_PRIO builds the kernels without)
+#if defined(FFC_NO_PRIO)
+#define FFC_PRIO(x)
+#else
+#define FFC_PRIO(x) if constexpr (GEO::NW > 1) B::template setprio<x>();
+#endif
 #pragma unroll 1
     for (int it = 0; it < iters; it++) {
       const int p = p0 + (RP ? it / npass : it) * GEO::UPW + u;
@@ -1428,6 +1444,7 @@ struct Body {
       const int hk = RP ? h * ps.R + ps.k0 : h;      // k_f row of this (head, pass)
       const bool act = p < p1;
       if (PROF) t0 = B::clock();
+      FFC_PRIO(1)
       if (act) {
         if constexpr (RP) {
           rows_in_rp<NC>(a, h, p, un, ps);
@@ -1437,6 +1454,7 @@ struct Body {
         }
         B::lds_fence();
         FFC_TICK(0)
+        FFC_PRIO(0)
         outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
         FFC_TICK(1)
       }
@@ -1455,7 +1473,10 @@ struct Body {
           uint8_t* zA = SZ ? z_slot(a.zsave, h, a.npair, pA) : nullptr;
           if (pA + 1 < p1) {
 #pragma unroll 1
-            for (int tt = 0; tt < 2; tt++) inner_tile2x<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
+            for (int tt = 0; tt < 2; tt++) {
+              if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
+              inner_tile2x<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
+            }
           } else {
             inner_tile2<false, SZ>(a, hk, wl * 2, R, ua, Pass(), zA);
           }
@@ -1475,9 +1496,11 @@ struct Body {
           for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2_sp(a, hk, un.wq * GEO::TPW + tt, R, Fs, un);
         } else if constexpr (GEO::N3 == GEO::N2) {
 #pragma unroll 1
-          for (int tt = 0; tt < GEO::TPW; tt += 2)
+          for (int tt = 0; tt < GEO::TPW; tt += 2) {
+            if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
             inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
                                 SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr);
+          }
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);
@@ -1493,11 +1516,13 @@ struct Body {
       FFC_TICK(3)
       unit_barrier();
       FFC_TICK(4)
+      FFC_PRIO(3)
       if constexpr (PREFETCH) { if (it + 1 < iters && p + GEO::UPW < p1) rows_load<NC>(a, h, p + GEO::UPW, un, X); }
       if (act) {
         outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
         B::lds_fence();
         FFC_TICK(5)
+        FFC_PRIO(2)
         if constexpr (SZ) {
           if (a.yraw) {
             ConvArgs ar = a;
@@ -1512,6 +1537,7 @@ struct Body {
       }
     }
 #undef FFC_TICK
+#undef FFC_PRIO
     if (PROF && a.prof) {
       const i32 lane = B::lane();
       unsigned long long* dst = a.prof + ((long long)wg_linear * GEO::WGW + B::wave()) * 8;

@@ -175,6 +175,8 @@ struct DevB {
   static FFC_FN u32 uconst(uint32_t c) { return c; }
   static FFC_FN i32 mul24(i32 a, i32 b) { return __mul24(a, b); }
   static FFC_FN unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }
+  // wave priority (s_setprio): see Body::outer_jobs
+  template <int P> static FFC_FN void setprio() { __builtin_amdgcn_s_setprio(P); }
   static FFC_FN U2 u2_from64(unsigned long long v) { return U2{(u32)v, (u32)(v >> 32)}; }
   // v_sin/v_cos run on the transcendental unit; consumers scheduled right behind them (packed f32 math in
   // particular) were observed to read stale operands on gfx950 (timing-dependent 1-3% errors, caught by a

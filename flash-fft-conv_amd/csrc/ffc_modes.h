@@ -556,10 +556,15 @@ struct Modes : Body<B, GEO, DT> {
   // accumulator registers are addressed statically.
   template <bool WITH_DX, bool RP = false>
   static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W,
-                               Pass ps = Pass(), bool z_stream = false) {
+                               Pass ps = Pass(), bool z_stream = false, bool second = false) {
 #pragma unroll 1
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
+#if !defined(FFC_NO_PRIO)
+      if constexpr (WITH_DX && GEO::NW > 1) {        // second half of the tile loop: the wave that is behind outranks its partner (bwd)
+        if (tt == GEO::TPW / 2) { if (second) B::template setprio<2>(); else B::template setprio<1>(); }
+      }
+#endif
       typename BD::KfRegs zv;
       z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
       typename BD::KfRegs kf;
@@ -810,6 +815,14 @@ struct Modes : Body<B, GEO, DT> {
       // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
       // DESIGN.md section 7)
       const bool have_z = d.zin != nullptr;
+      // wave priority by progress between two barriers (Body::outer_jobs has the measurements): row loads 1, phase A 0, the
+      // tile loops 3 then 1 (2 for the second-dispatched wave of the SIMD), phase C 3, stores 2
+      const bool second = wv >= 4;
+#if defined(FFC_NO_PRIO)
+#define FFC_BPRIO(x)
+#else
+#define FFC_BPRIO(x) if constexpr (GEO::NW > 1) B::template setprio<x>();
+#endif
 #pragma unroll 1
       for (int it = 0; it < iters; it++) {
         const int p = p0 + it * GEO::UPW + u;
@@ -817,6 +830,7 @@ struct Modes : Body<B, GEO, DT> {
 #if defined(FFC_BWD_PROF)
         if constexpr (!RP) pt0 = B::clock();
 #endif
+        FFC_BPRIO(1)
         // saved spectra (d.zin): the pair's first transform is skipped, its spectrum is read from the forward pass's copy
         const void* zp = !have_z ? (const void*)zs
                          : RP ? (const void*)BD::z_slot_rp(const_cast<void*>(d.zin), h, a.npair, act ? p : p0, a.R, k0)
@@ -853,6 +867,7 @@ struct Modes : Body<B, GEO, DT> {
             else BD::template rows_in<NCX>(ad, h, p, un);
             B::lds_fence();
             FFC_BTICK(6)
+            FFC_BPRIO(0)
             BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
             FFC_BTICK(7)
           }
@@ -862,11 +877,13 @@ struct Modes : Body<B, GEO, DT> {
             else BD::template rows_in<NCX>(av, h, p, un);
             B::lds_fence();
             FFC_BTICK(0)
+            FFC_BPRIO(0)
             BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
             FFC_BTICK(1)
           }
           BD::unit_barrier();
           FFC_BTICK(2)
+          FFC_BPRIO(3)
           if (act) {
             BD::template load_inner<false>(R, un);
 #pragma unroll 1
@@ -887,6 +904,7 @@ struct Modes : Body<B, GEO, DT> {
           FFC_BTICK(3)
           BD::unit_barrier();
           FFC_BTICK(4)
+          FFC_BPRIO(1)
           if (d.dpost) {
             if (act) {
               BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
@@ -903,15 +921,17 @@ struct Modes : Body<B, GEO, DT> {
             else BD::template rows_in<NCX>(ad, h, p, un);
             B::lds_fence();
             FFC_BTICK(6)
+            FFC_BPRIO(0)
             BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
             FFC_BTICK(7)
           }
         }
         BD::unit_barrier();
         FFC_BTICK(8)
+        FFC_BPRIO(3)
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z && FFC_Z_STREAM);
+          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z && FFC_Z_STREAM, second);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
@@ -919,10 +939,12 @@ struct Modes : Body<B, GEO, DT> {
         FFC_BTICK(9)
         BD::unit_barrier();
         FFC_BTICK(10)
+        FFC_BPRIO(3)
         if (act) {
           BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
           B::lds_fence();
           FFC_BTICK(11)
+          FFC_BPRIO(2)
           if constexpr (RP) {
             BD::template rows_out_rp<NCX>(ao, h, p, un, ps);
             if (d.dpre) BD::template rows_out_rp<NCX>(ap, h, p, un, ps);
@@ -942,6 +964,7 @@ struct Modes : Body<B, GEO, DT> {
       }
 #endif
 #undef FFC_BTICK
+#undef FFC_BPRIO
       w_acc_finish(slab, u, un, W);
     } else if (a.R > 1) {
       // inner-only multi-pass form: pass-major; du / dpregate accumulate over the passes (rows_out_rp)

@@ -184,6 +184,7 @@ struct SimB {
   static void lds_fence() {}
   static i32 mul24(const i32& a, const i32& b) { return a * b; }
   static unsigned long long clock() { return 0; }
+  template <int P> static void setprio() {}
   static U2 u2_from64(unsigned long long v) { U2 r; r.x = u32((uint32_t)v); r.y = u32((uint32_t)(v >> 32)); return r; }
   static void settle(f32&, f32&) {}
   static f32 i2f(const i32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = (float)a.v[i]; return r; }
