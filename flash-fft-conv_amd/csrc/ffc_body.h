@@ -1083,6 +1083,11 @@ struct Body {
   static FFC_FN uint8_t* z_slot(void* base, int h, int npair, int p) {
     return (uint8_t*)base + ((int64_t)h * npair + p) * ((int64_t)GEO::N * 4);
   }
+  // single-tile sizes (fft <= 2048): [H][tiles of G pairs][R passes] slots of 1024 complex values
+  static FFC_FN uint8_t* z_slot_small(void* base, int h, int npair, int q, int R, int k0) {
+    const int ntile = (npair + GEO::G - 1) / GEO::G;
+    return (uint8_t*)base + (((int64_t)h * ntile + q) * R + k0) * 4096;
+  }
   // multi-pass sizes: [H][npair][R passes][M]
   static FFC_FN uint8_t* z_slot_rp(void* base, int h, int npair, int p, int R, int k0) {
     return (uint8_t*)base + (((int64_t)h * npair + p) * R + k0) * ((int64_t)GEO::N * 4);
@@ -1103,10 +1108,13 @@ struct Body {
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) k.v[rq] = B::g_r128(kfh, ((hi + (tau * 8 + 2 * rq)) * 32 + c));
   }
-  template <bool IP = false>
-  static FFC_FN void inner_tile(const ConvArgs& a, int tau, const InnerRegs& R, Unit un, const KfRegs& kf, const InnerPass* ip = nullptr) {
+  // SZ: the tile's spectrum is kept for the backward pass at zs (single-tile sizes: one 4 KB slot per tile and pass, z_slot_small)
+  template <bool IP = false, bool SZ = false>
+  static FFC_FN void inner_tile(const ConvArgs& a, int tau, const InnerRegs& R, Unit un, const KfRegs& kf, const InnerPass* ip = nullptr,
+                                uint8_t* zs = nullptr) {
     A16 re, im;
     tile_fwd<true, IP>(tau, R, un, re, im, ip);
+    if constexpr (SZ) z_store(zs, 0, re, im, FFC_Z_STREAM);
     // (x) k_f
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
@@ -1588,8 +1596,15 @@ struct Body {
             load_kf(a, h * a.R + k0, 0, kf);
             rows_in_rp<NCH>(a, h, q, un, ps);
             B::lds_fence();
-            inner_tile<true>(a, 0, R, un, kf, &ip);
+            inner_tile<true, SZ>(a, 0, R, un, kf, &ip, SZ ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
             B::lds_fence();
+            if constexpr (SZ) {
+              if (a.yraw) {      // output before the postgate multiply (dpostgate = dout * this)
+                ConvArgs ar = a;
+                ar.y = a.yraw; ar.postgate = nullptr; ar.sby = (int64_t)a.H * a.L;
+                rows_out_rp<NCH>(ar, h, q, un, ps);
+              }
+            }
             rows_out_rp<NCH>(a, h, q, un, ps);
             B::lds_fence();
           }
@@ -1605,8 +1620,15 @@ struct Body {
           load_kf(a, h, 0, kf);
           rows_in(a, h, q, un);
           B::lds_fence();
-          inner_tile(a, 0, R, un, kf);
+          inner_tile<false, SZ>(a, 0, R, un, kf, nullptr, SZ ? z_slot_small(a.zsave, h, a.npair, q, 1, 0) : nullptr);
           B::lds_fence();
+          if constexpr (SZ) {
+            if (a.yraw) {
+              ConvArgs ar = a;
+              ar.y = a.yraw; ar.postgate = nullptr; ar.sby = (int64_t)a.H * a.L;
+              rows_out(ar, h, q, un);
+            }
+          }
           rows_out(a, h, q, un);
         }
       }

@@ -97,10 +97,16 @@ struct ConvLaunch {
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else if constexpr (GEO::N == 1024) {
         constexpr int lds = GEO::LDS_BYTES + 2 * BD::IPASS_BYTES;
-        int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
-        if (rc) return rc;
         const int cap = (a.persist > 0 && a.persist < (1 << 29)) ? 2 * a.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
-        hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
+        if (a.zsave) {
+          int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false, true>, lds);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false, true>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
+        } else {
+          int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false>, lds);
+          if (rc) return rc;
+          hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
+        }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_rp_kernel launch: ") + hipGetErrorString(e));
       } else {
@@ -140,7 +146,11 @@ struct ConvLaunch {
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel (spectrum-saving) launch: ") + hipGetErrorString(e));
       } else {
-        return ffc_fail("spectrum buffer on a plan without an outer digit");
+        int rc = ffc_set_lds(conv_kernel<GEO, DT, false, true>, GEO::LDS_BYTES);
+        if (rc) return rc;
+        hipLaunchKernelGGL((conv_kernel<GEO, DT, false, true>), dim3(grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES, st, a);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : ffc_fail(std::string("conv_kernel (spectrum-saving, single tile) launch: ") + hipGetErrorString(e));
       }
     }
     // HALF variant (own register allocation): 32-point outer digit and L <= N/2, only E rows < 16 carry data
@@ -164,9 +174,13 @@ static inline bool ffc_stride_ok(int64_t* sb, int64_t B, int64_t H, int64_t L) {
   return *sb >= H * L && (B - 1) * *sb + H * L < ((int64_t)1 << 31);
 }
 
-// spectra saved for the backward pass: [H][npair][N] complex values of the plan dtype; 0 = this plan has no such path
+// spectra saved for the backward pass: [H][npair][N] complex values of the plan dtype (single-tile sizes: see below)
 extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
-  if (!p || p->hp.N1 <= 1 || B <= 0 || H <= 0) return 0;
+  if (!p || B <= 0 || H <= 0) return 0;
+  if (p->hp.N1 <= 1) {      // single-tile sizes (fft <= 2048): [H][tiles of G pairs][R passes] slots of 1024 complex values
+    const int64_t G = (32 / p->hp.N2) * (32 / p->hp.N3);
+    return H * (((B + 1) / 2 + G - 1) / G) * p->hp.R * 4096;
+  }
   return ((B + 1) / 2) * H * (int64_t)p->hp.N * 4;        // (hp.N = the plan's fft size, R passes x the kernel size)
 }
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,

@@ -987,15 +987,21 @@ struct Modes : Body<B, GEO, DT> {
               A16 re, im;
               typename BD::KfRegs kf;
               BD::load_kf(a, h * a.R + k0, 0, kf);
-              BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
-              B::lds_fence();
-              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
-              z_pack(re, im, zv);
-              B::lds_fence();
+              typename BD::KfRegs zk;
+              if (d.zin) {       // spectrum saved by the forward pass: the tile's first transform is skipped
+                z_load(BD::z_slot_small(const_cast<void*>(d.zin), h, a.npair, q, a.R, k0), 0, zk, FFC_Z_STREAM);
+              } else {
+                BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
+                B::lds_fence();
+                BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+                z_pack(re, im, zv);
+                B::lds_fence();
+              }
               BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
               B::lds_fence();
               BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
-              w_add(wre, wim, zv, re, im);
+              if (d.zin) w_add_k(wre, wim, zk, re, im);
+              else w_add(wre, wim, zv, re, im);
               kf_conj_mul(kf, re, im);
               B::lds_fence();
               BD::template tile_inv<true, false, true>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
@@ -1021,22 +1027,21 @@ struct Modes : Body<B, GEO, DT> {
           A16 re, im;
           typename BD::KfRegs kf;
           BD::load_kf(a, h, 0, kf);
-          BD::rows_in(av, h, q, un);
-          B::lds_fence();
-          BD::tile_fwd(0, R, un, re, im);
-          z_pack(re, im, zv);
-          B::lds_fence();
+          typename BD::KfRegs zk;
+          if (d.zin) {       // spectrum saved by the forward pass: the tile's first transform is skipped
+            z_load(BD::z_slot_small(const_cast<void*>(d.zin), h, a.npair, q, 1, 0), 0, zk, FFC_Z_STREAM);
+          } else {
+            BD::rows_in(av, h, q, un);
+            B::lds_fence();
+            BD::tile_fwd(0, R, un, re, im);
+            z_pack(re, im, zv);
+            B::lds_fence();
+          }
           BD::rows_in(ad, h, q, un);
           B::lds_fence();
           BD::tile_fwd(0, R, un, re, im);
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            u32 pr = zv.r[r >> 1], pi = zv.i[r >> 1];
-            f32 ur = (r & 1) ? B::template unpack_hi<DT>(pr) : B::template unpack_lo<DT>(pr);
-            f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
-            wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
-            wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
-          }
+          if (d.zin) w_add_k(wre, wim, zk, re, im);
+          else w_add(wre, wim, zv, re, im);
           kf_conj_mul(kf, re, im);
           B::lds_fence();
           BD::tile_inv(a.s_inv, 0, R, un, re, im);
@@ -1059,6 +1064,20 @@ struct Modes : Body<B, GEO, DT> {
       f32 ui = (r & 1) ? B::template unpack_hi<DT>(pi) : B::template unpack_lo<DT>(pi);
       wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
       wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
+    }
+  }
+  // the same with Zv in the saved-spectrum format (z_store: one (re, im) dtype pair per word)
+  static FFC_FN void w_add_k(A16& wre, A16& wim, const typename BD::KfRegs& z, const A16& re, const A16& im) {
+#pragma unroll
+    for (int rq = 0; rq < 4; rq++) {
+      u32 wv[4] = {z.v[rq].x, z.v[rq].y, z.v[rq].z, z.v[rq].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * rq + q;
+        f32 ur = B::template unpack_lo<DT>(wv[q]), ui = B::template unpack_hi<DT>(wv[q]);
+        wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
+        wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
+      }
     }
   }
   static FFC_FN void store_w(float* slab, const A16& re, const A16& im) {

@@ -118,10 +118,14 @@ def _conv_sparse(plan, u, kf, pregate, postgate, conj, rows):
     return y
 
 
-def _spectrum_buffer(plan, B, H, device):
+def _spectrum_buffer(plan, B, H, device, gated=True):
     """Buffer for the spectra FFT(u * pregate) that the forward pass keeps for the backward pass (ffc_conv_fwd_z / ffc_conv_bwd_z),
-    or None: plan without that path (fft < 4096, multi-pass and HBM-level sizes), or no memory for it (the caller then takes the
-    recomputing path, like the reference)."""
+    or None: no memory for it (the caller then takes the recomputing path, like the reference).  Every fused plan has the path:
+    [H][pair][fft size] complex values, for the single-tile sizes (fft <= 2048) one 4 KB slot per tile and pass."""
+    # single-tile sizes without gates: not worth it (measured at B64 H768, fwd + bwd: fft 256 +5 %, 1024 +-0; gated -9 % / -17 %
+    # because the saved pre-postgate output also replaces the extra forward launch that produces dpostgate there; 2048 -8 % / -13 %)
+    if plan.seqlen <= 1024 and not gated:
+        return None
     n = _lib.lib().ffc_spectrum_bytes(plan.handle, B, H)
     if n <= 0:
         return None
@@ -379,7 +383,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if rows:
                 out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
             elif mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
-                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device)
+                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated)
                 if z is not None and ctx.gated:
                     try:
                         yraw = torch.empty_like(u)

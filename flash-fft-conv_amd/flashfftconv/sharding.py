@@ -136,7 +136,7 @@ class _HipOps:
 
     def conv_keep(self, u, kf, pre, post):
         """training forward: (out, kept) with kept = (spectra, output before the postgate) or None (FlashFFTConv.save_spectrum)"""
-        z = self.C._spectrum_buffer(self.plan, u.shape[0], u.shape[1], u.device) if self.mod.save_spectrum else None
+        z = self.C._spectrum_buffer(self.plan, u.shape[0], u.shape[1], u.device, pre is not None) if self.mod.save_spectrum else None
         if z is None:
             return self.conv(u, kf, pre, post), None
         yraw = torch.empty_like(u) if pre is not None else None

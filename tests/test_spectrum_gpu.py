@@ -9,7 +9,7 @@ from oracle.torch_ref import ref_fft_conv
 from tests.test_flashfftconv_gpu import rel, make_inputs, stable, REL
 
 pytestmark = pytest.mark.gpu
-SIZES = [4096, 8192, 16384, 32768, 65536, 131072]      # the last two: 2 / 4 passes of the fused 32768 kernel
+SIZES = [256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072]      # 2048: 2 passes of the 1024 kernel; the last two: 2 / 4 passes of the 32768 kernel
 SHAPES = [(4, 16), (3, 7), (1, 5), (16, 24)]      # (B, H): even, odd batch, single row, several chunks
 SHAPES_BIG = [(4, 8), (3, 5)]
 
@@ -24,7 +24,11 @@ def _call_pair(N, B, H, L, dtype, gated):
     plan = FlashFFTConv(N, dtype=dtype).cuda()._get_plan(u.device)
     kf = C._kernel_fft(plan, k)
     zb = lib.ffc_spectrum_bytes(plan.handle, B, H)
-    assert zb == ((B + 1) // 2) * H * N * 4
+    if N >= 4096:
+        assert zb == ((B + 1) // 2) * H * N * 4
+    else:       # single-tile sizes: 4 KB slots per tile of G pairs (and pass)
+        G = {256: 4, 512: 2, 1024: 1, 2048: 1}[N]
+        assert zb == H * -(-((B + 1) // 2) // G) * (2 if N == 2048 else 1) * 4096
     z = torch.empty(zb, dtype=torch.uint8, device="cuda")
     ws0 = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda"); ws1 = torch.empty_like(ws0)
     y0, y1 = torch.full_like(u, 7.0), torch.full_like(u, 9.0)
@@ -59,7 +63,11 @@ def test_saved_spectrum_equals_recompute(N, gated, dtype):
         for L in (N // 2, N, N // 2 - 8, N - 3):      # padded, full, ragged fast path, ragged slow path (L % 8 != 0)
             (y0, o0, dk0), (y1, o1, dk1) = _call_pair(N, B, H, L, dtype, gated)
             tag = f"fft {N} B{B} H{H} L{L} gated={gated} {dtype}"
-            assert torch.equal(y0, y1), f"{tag}: forward output changed by the spectrum store"
+            step = 1e-2 if dtype == torch.bfloat16 else 2e-3
+            if N >= 4096:
+                assert torch.equal(y0, y1), f"{tag}: forward output changed by the spectrum store"
+            else:       # single-tile kernels: the two instantiations contract the fp32 k_f product differently (last-bit steps)
+                assert rel(y1, y0) < step / 4, f"{tag}: forward output rel {rel(y1, y0):.2e}"
             assert torch.equal(o0[0], o1[0]), f"{tag}: du"
             # same spectrum up to the last bit of its rounding to the plan dtype (the fp32 schedule of the two kernels differs):
             # outputs that are rounded once more (dpostgate) move by single steps of the dtype
@@ -91,7 +99,10 @@ def test_module_gradients_with_saved_spectrum(N, gated, dtype):
         g2 = torch.autograd.grad(out, leaves, dout)
         assert all(torch.equal(a, b) for a, b in zip(g, g2)), "second backward through a retained graph differs"
         grads[save] = (out.detach(), g)
-    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1][0], grads[False][1][0])
+    if N >= 4096:
+        assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1][0], grads[False][1][0])
+    else:       # single-tile kernels: equal to last-bit steps (see test_saved_spectrum_equals_recompute)
+        assert rel(grads[True][0], grads[False][0]) < REL[dtype] / 4 and rel(grads[True][1][0], grads[False][1][0]) < REL[dtype] / 4
     lc = [u.clone().requires_grad_(True), k.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in gates]
     fwd = (lambda: (ref_fft_conv(lc[0] * lc[2], lc[1], n=N) * lc[3],)) if gated else (lambda: (ref_fft_conv(lc[0], lc[1], n=N),))
     (ref,) = stable(fwd, "forward")
@@ -105,22 +116,16 @@ def test_module_gradients_with_saved_spectrum(N, gated, dtype):
             assert rel(g[2], gref[2]) < tol and rel(g[3], gref[3]) < tol, f"gate gradients (save_spectrum={save})"
 
 
-def test_no_spectrum_path_for_other_plans():
+def test_spectrum_buffer_is_refused_when_misaligned_or_missing():
     from flashfftconv import FlashFFTConv, _lib
     lib = _lib.lib()
-    for N in (256, 1024, 2048):
-        plan = FlashFFTConv(N, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
-        assert lib.ffc_spectrum_bytes(plan.handle, 4, 8) == 0
     plan = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
     u = torch.zeros(2, 8, 512, device="cuda", dtype=torch.bfloat16); kf = torch.zeros(8, plan.kf_elems, 2, device="cuda", dtype=torch.bfloat16)
     z = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")
-    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), _lib.ptr(z), None, 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
+    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), z.data_ptr() + 4, None, 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
     assert rc != 0 and b"spectrum" in lib.ffc_last_error()
-    # small sizes and gated calls train through the recomputing path
-    conv = FlashFFTConv(1024, dtype=torch.bfloat16).cuda()
-    uu = (torch.randn(2, 8, 512, device="cuda") * 0.1).bfloat16().requires_grad_(True); kk = torch.randn(8, 512, device="cuda").requires_grad_(True)
-    conv(uu, kk).sum().backward()
-    assert uu.grad is not None and kk.grad is not None
+    rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), None, None, 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
+    assert rc != 0
 
 
 @pytest.mark.gpu
