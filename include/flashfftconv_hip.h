@@ -93,8 +93,10 @@ int ffc_conv_bwd_gated_strided(const ffc_plan* plan, const void* dout, const voi
  * pair's spectrum FFT(u * pregate) (plan dtype, internal order, ffc_spectrum_bytes() bytes: 2x the size of u at L = N/2) and
  * ffc_conv_bwd_z reads it instead of transforming u again: one of the backward's three transforms per pair, its rows of u
  * and its scratch round trip disappear.  du / dpregate come out bit for bit as from ffc_conv_bwd_gated_strided; dk and dpostgate
- * agree to the rounding of the spectrum (the forward and the backward kernel schedule the same fp32 operations differently).  Fused single-pass sizes with an outer digit only (fft 4096 ... 32768):
- * ffc_spectrum_bytes() returns 0 for every other plan.
+ * agree to the rounding of the spectrum (the forward and the backward kernel schedule the same fp32 operations differently).
+ * Every fused plan has the pair (fft 256 ... 131072); layout [H][pair][fft size] complex values, for the single-tile sizes
+ * (fft <= 2048) one 4 KB slot per tile of G pairs and pass.  There the forward output of ffc_conv_fwd_z agrees with
+ * ffc_conv_fwd to last-bit steps of the dtype (two instantiations of the same arithmetic), for fft >= 4096 bit for bit.
  * y_raw (nullable; contiguous (B,H,L) dtype): the forward output before the postgate multiply.  The gated backward's
  * dpostgate is dout * y_raw -- with it the caller passes dpost = NULL to ffc_conv_bwd_z and that kernel runs no third transform. */
 int64_t ffc_spectrum_bytes(const ffc_plan* plan, int64_t B, int64_t H);
