@@ -5,7 +5,8 @@ The model is the reference's `HyenaDNAModel` backbone (examples/hyena-dna/hyenad
 n_layer x [LayerNorm -> HyenaOperator -> +res -> LayerNorm -> MLP(4x, GELU) -> +res] -> LayerNorm) with random weights
 (no network: no HuggingFace checkpoint) and, like the reference's flash model, a static long filter (`HyenaFilter.filter`
 returns the k_ones buffer, :190-201).  The Hyena operator comes in three forms:
-   fused    this package's FlashHyenaOp (short conv + gated FFT conv, slices read in place)
+   fused    this package's FlashHyenaMixer (projections as batched GEMMs on transposed views, short conv + gated FFT conv with
+            the slices read in place: no layout copy, no elementwise kernel)
    dropin   the reference CALLER code verbatim on this package's modules (FlashDepthWiseConv1d, x1*v, .contiguous(),
             FlashFFTConv, *x2): hyenadna_flashfftconv.py:269-289 -- the drop-in claim on a real caller
    torch    the reference's non-flash path: nn.Conv1d + torch.fft (hyenadna_standalone.py fftconv)
@@ -22,7 +23,7 @@ sys.path[:0] = [os.path.join(ROOT, "flash-fft-conv_amd"), ROOT]
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d, FlashHyenaOp
+from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d, FlashHyenaMixer
 
 # name: (d_model, n_layer, max_length, batch[, d_inner / d_model, dtype])   -- sizes of the published HyenaDNA checkpoints
 # (huggingface.py:160-175) and the Hyena LM of examples/hyena/configs/experiment/pile/hyena.yaml
@@ -56,7 +57,7 @@ class HyenaOperator(nn.Module):
         self.register_buffer("k", static_filter(d_model, l_max))
         n = fft_size_for(l_max)
         if form == "fused":
-            self.op = FlashHyenaOp(d_model, n, self.short_filter.weight, self.short_filter.bias, dtype=dtype)
+            self.mixer = FlashHyenaMixer(d_model, n, self.in_proj, self.out_proj, self.short_filter.weight, self.short_filter.bias, dtype=dtype)
         elif form == "dropin":
             self.flash_short_filter = FlashDepthWiseConv1d(3 * d_model, 3, padding=1, weights=self.short_filter.weight,
                                                            bias=self.short_filter.bias, dtype=dtype)
@@ -64,12 +65,12 @@ class HyenaOperator(nn.Module):
 
     def forward(self, u):
         l = u.size(-2)
+        if self.form == "fused":      # projections as batched GEMMs on transposed views, gates read in place: no layout copy
+            return self.mixer(u, self.k[:, :l])
         u = u.transpose(-1, -2)
         u = (self.in_proj.weight @ u).contiguous()        # the reference drops the in_proj bias here too (:270)
         k = self.k[:, :l]
-        if self.form == "fused":
-            y = self.op(u, k)
-        elif self.form == "dropin":                       # hyenadna_flashfftconv.py:272-284, verbatim
+        if self.form == "dropin":                       # hyenadna_flashfftconv.py:272-284, verbatim
             uc = self.flash_short_filter(u)[..., :l]
             x1, x2, v = uc.split(self.d_model, dim=1)
             x1v = x1 * v

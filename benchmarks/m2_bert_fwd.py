@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from flashfftconv import FlashFFTConv, FlashDepthWiseConv1d
-from flashfftconv.hyena import gated_conv_from_slices
+from flashfftconv.hyena import gated_conv_from_slices, project_in, project_out
 
 # name: (d_model, n_layer, seq_len, batch)   -- M2-BERT-base 80M (12 layers x 768) at its four published context lengths
 CONFIGS = {"base-128": (768, 12, 128, 32), "base-2k": (768, 12, 2048, 8), "base-8k": (768, 12, 8192, 4),
@@ -52,14 +52,15 @@ class SequenceMixer(nn.Module):
 
     def forward(self, u):
         B, L, H = u.shape
-        u = u.transpose(-1, -2)
-        x1x2v = (self.in_linear.weight @ u).contiguous()          # the reference drops the in_linear bias (:124-125)
         k, k2 = self.filter.float(), self.filter2.float()
-        if self.form == "fused":
-            uc = self.short_filter(x1x2v)
+        if self.form == "fused":      # projections as batched GEMMs on transposed views: no layout copy on either side
+            uc = self.short_filter(project_in(self.in_linear.weight, u))
             y = gated_conv_from_slices(self.flashfftconv, uc, k)  # x2 * conv(x1 * v, k), slices read in place
             y = y + self.flashfftconv(uc[:, 2 * H:].contiguous(), k2)
-        elif self.form == "dropin":                               # :128-170, verbatim
+            return project_out(self.out_linear.weight, self.out_linear.bias, y)
+        u = u.transpose(-1, -2)
+        x1x2v = (self.in_linear.weight @ u).contiguous()          # the reference drops the in_linear bias (:124-125)
+        if self.form == "dropin":                               # :128-170, verbatim
             x1x2v = self.short_filter(x1x2v)
             x1, x2, v = x1x2v.split(self.d_model, dim=1)
             x1v = x1 * v

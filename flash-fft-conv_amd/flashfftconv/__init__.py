@@ -3,8 +3,8 @@
 from .conv import FlashFFTConv
 from .depthwise_1d import FlashDepthWiseConv1d
 from .sparse_conv import PartialFFTConv, FrequencySparseFFTConv
-from .hyena import FlashHyenaOp, gated_conv_from_slices
+from .hyena import FlashHyenaOp, FlashHyenaMixer, gated_conv_from_slices, project_in, project_out
 
 FlashDepthwiseConv1d = FlashDepthWiseConv1d  # README spelling of the reference
 __all__ = ["FlashFFTConv", "FlashDepthWiseConv1d", "FlashDepthwiseConv1d", "PartialFFTConv", "FrequencySparseFFTConv",
-           "FlashHyenaOp", "gated_conv_from_slices"]
+           "FlashHyenaOp", "FlashHyenaMixer", "gated_conv_from_slices", "project_in", "project_out"]

@@ -134,3 +134,67 @@ class FlashHyenaOp(torch.nn.Module):
     def forward(self, x1x2v, k):
         uc = self.short_filter(x1x2v)
         return gated_conv_from_slices(self.flashfftconv, uc, k)
+
+
+_LOOP_MAX_BATCH = 16
+
+
+def project_in(weight, u, bias=None):
+    """in-projection of a (B, L, D) activation straight into the channels-first layout the convolutions read:
+    (C, D) x (B, L, D) -> (B, C, L), one plain 2-D GEMM per batch row on the transposed view u[b].t(), written into its slice of
+    the output.  The reference callers write `self.in_proj.weight @ u.transpose(-1, -2)` (hyenadna_flashfftconv.py:269-270,
+    monarch_mixer_sequence_mixer_flashfftconv.py:124-125, bias dropped there too): torch.matmul folds that into a (B*L, D) x
+    (D, C) GEMM and then copies the result into (B, C, L) with a strided elementwise kernel -- 224 of its 267 us at B2 L32K
+    D256 on MI355X, 15 % of a HyenaDNA layer (benchmarks/scratch/proj_probe.py).
+    (Not torch.bmm on the broadcast weight: on this ROCm 7.0 / PyTorch 2.10 stack the BATCHED GEMM with a transposed-view
+    operand writes out of bounds at D = 768, L >= 8192 -- hipBLASLt and rocBLAS alike, the reference's own matmul form included;
+    benchmarks/scratch/bmm_fault2.py.  The 2-D GEMM is the path every nn.Linear takes.)"""
+    B, L, _ = u.shape
+    if B > _LOOP_MAX_BATCH:      # many short sequences: one GEMM + the layout copy, which is small there
+        out = torch.nn.functional.linear(u, weight).transpose(-1, -2).contiguous()
+        return out if bias is None else out + bias.view(1, -1, 1)
+    if torch.is_grad_enabled() and (u.requires_grad or weight.requires_grad):
+        out = torch.stack([torch.mm(weight, u[b].t()) for b in range(B)])      # autograd-visible form (same GEMMs, + the stack copy)
+    else:
+        out = torch.empty(B, weight.shape[0], L, dtype=u.dtype, device=u.device)
+        for b in range(B):
+            torch.mm(weight, u[b].t(), out=out[b])
+    if bias is not None:
+        out = out + bias.view(1, -1, 1)
+    return out
+
+
+def project_out(weight, bias, y):
+    """out-projection of a channels-first (B, D, L) result back to (B, L, C): nn.Linear on y.transpose(-1, -2) first copies
+    the transposed view (55 of 88 us at the shape above); a 2-D GEMM per batch row reads y[b].t() as its transposed operand."""
+    B, _, L = y.shape
+    if B > _LOOP_MAX_BATCH:
+        return torch.nn.functional.linear(y.transpose(-1, -2), weight, bias)
+    wt = weight.t()
+    if torch.is_grad_enabled() and (y.requires_grad or weight.requires_grad):
+        rows = [torch.mm(y[b].t(), wt) if bias is None else torch.addmm(bias, y[b].t(), wt) for b in range(B)]
+        return torch.stack(rows)
+    out = torch.empty(B, L, weight.shape[0], dtype=y.dtype, device=y.device)
+    for b in range(B):
+        if bias is None:
+            torch.mm(y[b].t(), wt, out=out[b])
+        else:
+            torch.addmm(bias, y[b].t(), wt, out=out[b])
+    return out
+
+
+class FlashHyenaMixer(torch.nn.Module):
+    """The whole order-2 Hyena operator of the reference callers (hyenadna_flashfftconv.py:228-289 HyenaOperator.forward):
+    in_proj -> short depthwise conv -> x2 * fftconv(x1 * v, k) -> out_proj, on (B, L, D) activations, with no layout copy:
+    the two projections are GEMMs on transposed views (project_in / project_out), the gates are read in place
+    (FlashHyenaOp).  `in_proj` (D -> 3D) and `out_proj` (D -> D) are the caller's nn.Linear modules (shared, not copied);
+    the in-projection bias is not applied, as in the reference (`self.in_proj.weight @ u`)."""
+
+    def __init__(self, d_model, fft_size, in_proj, out_proj, short_filter_weight, short_filter_bias, dtype=torch.bfloat16, device=None):
+        super().__init__()
+        self.in_proj, self.out_proj = in_proj, out_proj
+        self.op = FlashHyenaOp(d_model, fft_size, short_filter_weight, short_filter_bias, dtype=dtype, device=device)
+
+    def forward(self, u, k):
+        y = self.op(project_in(self.in_proj.weight, u), k)
+        return project_out(self.out_proj.weight, self.out_proj.bias, y)

@@ -73,3 +73,37 @@ def test_hyena_op_eval_and_errors():
     assert y.shape == (2, D, L) and torch.isfinite(y).all()
     with pytest.raises(RuntimeError):
         gated_conv_from_slices(FlashFFTConv(4096, dtype=torch.bfloat16).cuda(), u[:, :64], k)    # not 3*D channels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_mixer_equals_the_reference_operator(dtype):
+    """FlashHyenaMixer (projections as batched GEMMs on transposed views) == the reference callers' HyenaOperator.forward
+    (hyenadna_flashfftconv.py:266-289) written with this package's drop-in modules, forward and gradients"""
+    from flashfftconv import FlashHyenaMixer, FlashFFTConv, FlashDepthWiseConv1d
+    torch.manual_seed(5)
+    B, L, D, fft = 2, 2048, 64, 4096
+    inp = torch.nn.Linear(D, 3 * D).cuda().to(dtype); outp = torch.nn.Linear(D, D).cuda().to(dtype)
+    sf = torch.nn.Conv1d(3 * D, 3 * D, 3, padding=2, groups=3 * D).cuda()
+    k = (torch.randn(D, L, device="cuda") * 0.02).requires_grad_(True)
+    u = (torch.randn(B, L, D, device="cuda") * 0.5).to(dtype).requires_grad_(True)
+    mixer = FlashHyenaMixer(D, fft, inp, outp, sf.weight.detach(), sf.bias.detach(), dtype=dtype, device="cuda").cuda()
+    short = FlashDepthWiseConv1d(3 * D, 3, padding=1, weights=sf.weight.detach(), bias=sf.bias.detach(), dtype=dtype).cuda()
+    conv = FlashFFTConv(fft, dtype=dtype).cuda()
+
+    def reference(u, k):
+        x = inp.weight @ u.transpose(-1, -2)
+        uc = short(x)[..., :L]
+        x1, x2, v = uc.split(D, dim=1)
+        y = conv((x1 * v).contiguous(), k) * x2
+        return outp(y.transpose(-1, -2))
+    y = mixer(u, k); yr = reference(u, k)
+    assert y.shape == (B, L, D) and y.is_contiguous()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm()).item()
+    assert rel(y, yr) < tol, rel(y, yr)
+    dy = torch.randn_like(y) * 0.1
+    g = torch.autograd.grad(y, [u, k, inp.weight, outp.weight, outp.bias], dy)
+    gr = torch.autograd.grad(yr, [u, k, inp.weight, outp.weight, outp.bias], dy)
+    for a, b, n in zip(g, gr, ("du", "dk", "d in_proj.weight", "d out_proj.weight", "d out_proj.bias")):
+        assert rel(a, b) < 2 * tol, f"{n}: {rel(a, b):.3e}"
