@@ -118,6 +118,7 @@ def ev_time(fn, iters):
 
 
 FORMS = ("torch", "dropin", "fused")
+TRAIN = False
 
 
 def run(name, dtype=torch.bfloat16):
@@ -132,13 +133,29 @@ def run(name, dtype=torch.bfloat16):
         for m in model.modules():                    # the long filter stays fp32 (the reference passes fp32 k to FlashFFTConv)
             if isinstance(m, HyenaOperator):
                 m.k = m.k.float()
-        with torch.no_grad():
+        if TRAIN:       # --train: forward + backward of the backbone (training mode: the convolutions keep their spectra)
+            model.train()
+            params = [p for p in model.parameters() if p.requires_grad]
+            for m in model.modules():                # the long filter is a learned quantity in training (HyenaFilter's MLP output)
+                if isinstance(m, HyenaOperator):
+                    m.k.requires_grad_(True); params.append(m.k)
             y = model(ids)
-            ms = ev_time(lambda: model(ids), 3 if L > 200000 else 10)
+            dy = torch.randn_like(y) * 0.01
+
+            def step():
+                for p in params:
+                    p.grad = None
+                model(ids).backward(dy)
+            ms = ev_time(step, 3 if L > 200000 else 10)
+            y = y.detach()
+        else:
+            with torch.no_grad():
+                y = model(ids)
+                ms = ev_time(lambda: model(ids), 3 if L > 200000 else 10)
         outs[form] = y.float()
         diff = ((outs[form] - outs["torch"]).norm() / outs["torch"].norm()).item() if "torch" in outs else float("nan")
         print(json.dumps({"model": f"hyenadna-{name}", "d_model": d_model, "n_layer": n_layer, "seqlen": L, "batch": B,
-                          "fft_size": fft_size_for(L), "form": form, "dtype": str(dtype).split(".")[-1], "ms": round(ms, 3),
+                          "fft_size": fft_size_for(L), "form": form, "pass": "fwd+bwd" if TRAIN else "fwd", "dtype": str(dtype).split(".")[-1], "ms": round(ms, 3),
                           "tokens_per_ms": round(B * L / ms, 1), "seqs_per_s": round(B / (ms * 1e-3), 2),
                           "rel_diff_vs_torch": round(diff, 5)}), flush=True)
         del model
@@ -147,6 +164,9 @@ def run(name, dtype=torch.bfloat16):
 
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "--train":
+        TRAIN = True
+        args = args[1:]
     if args and args[0].startswith("--forms="):      # e.g. --forms=dropin under rocprofv3 --stats: one form's kernels only
         FORMS = tuple(args[0][8:].split(","))
         args = args[1:]

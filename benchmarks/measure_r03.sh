@@ -23,6 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg3 -o s -- python $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/f1m -o s -- python $R/benchmarks/prof_one.py 1048576 16 96 524288 both > $O/f1m.log 2>&1
 cd $R
 python benchmarks/hyena_dna_fwd.py tiny-16k small-32k medium-160k large-1m hyena-pile-4k > $O/hyena.jsonl 2> $O/hyena.err
+python benchmarks/hyena_dna_fwd.py --train tiny-16k small-32k medium-160k hyena-pile-4k > $O/hyena_train.jsonl 2> $O/hyena_train.err
 python benchmarks/m2_bert_fwd.py > $O/m2.jsonl 2> $O/m2.err
 python benchmarks/short_probe.py > $O/short_probe.txt 2>&1
 python benchmarks/ab_spectrum.py > $O/spectrum.txt 2>&1

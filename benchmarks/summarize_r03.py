@@ -24,7 +24,7 @@ if tr:
         fh.write("kernel,start_ns,end_ns,duration_us\n")
         for r in keep[-400:]:
             fh.write(f"{r['Kernel_Name'][:60].replace(',', ';')},{r['Start_Timestamp']},{r['End_Timestamp']},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f}\n")
-for src, dst in (("hyena.jsonl", "r03_hyena_fwd.jsonl"), ("m2.jsonl", "r03_m2_bert_fwd.jsonl"), ("short_probe.txt", "r03_short_probe.txt"),
+for src, dst in (("hyena.jsonl", "r03_hyena_fwd.jsonl"), ("hyena_train.jsonl", "r03_hyena_train.jsonl"), ("m2.jsonl", "r03_m2_bert_fwd.jsonl"), ("short_probe.txt", "r03_short_probe.txt"),
                  ("spectrum.txt", "r03_spectrum.txt")):
     if os.path.exists(f"{O}/{src}"):
         shutil.copy(f"{O}/{src}", f"{P}/{dst}")

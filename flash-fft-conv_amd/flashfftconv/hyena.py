@@ -139,48 +139,93 @@ class FlashHyenaOp(torch.nn.Module):
 _LOOP_MAX_BATCH = 16
 
 
-def project_in(weight, u, bias=None):
-    """in-projection of a (B, L, D) activation straight into the channels-first layout the convolutions read:
-    (C, D) x (B, L, D) -> (B, C, L), one plain 2-D GEMM per batch row on the transposed view u[b].t(), written into its slice of
-    the output.  The reference callers write `self.in_proj.weight @ u.transpose(-1, -2)` (hyenadna_flashfftconv.py:269-270,
-    monarch_mixer_sequence_mixer_flashfftconv.py:124-125, bias dropped there too): torch.matmul folds that into a (B*L, D) x
-    (D, C) GEMM and then copies the result into (B, C, L) with a strided elementwise kernel -- 224 of its 267 us at B2 L32K
-    D256 on MI355X, 15 % of a HyenaDNA layer (benchmarks/scratch/proj_probe.py).
-    (Not torch.bmm on the broadcast weight: on this ROCm 7.0 / PyTorch 2.10 stack the BATCHED GEMM with a transposed-view
-    operand writes out of bounds at D = 768, L >= 8192 -- hipBLASLt and rocBLAS alike, the reference's own matmul form included;
-    benchmarks/scratch/bmm_fault2.py.  The 2-D GEMM is the path every nn.Linear takes.)"""
-    B, L, _ = u.shape
-    if B > _LOOP_MAX_BATCH:      # many short sequences: one GEMM + the layout copy, which is small there
-        out = torch.nn.functional.linear(u, weight).transpose(-1, -2).contiguous()
-        return out if bias is None else out + bias.view(1, -1, 1)
-    if torch.is_grad_enabled() and (u.requires_grad or weight.requires_grad):
-        out = torch.stack([torch.mm(weight, u[b].t()) for b in range(B)])      # autograd-visible form (same GEMMs, + the stack copy)
-    else:
+class _ProjectIn(torch.autograd.Function):
+    """(C, D) x (B, L, D) -> (B, C, L): one 2-D GEMM per batch row on the transposed view, forward and backward"""
+
+    @staticmethod
+    def forward(ctx, weight, u):
+        B, L, _ = u.shape
         out = torch.empty(B, weight.shape[0], L, dtype=u.dtype, device=u.device)
         for b in range(B):
             torch.mm(weight, u[b].t(), out=out[b])
-    if bias is not None:
-        out = out + bias.view(1, -1, 1)
-    return out
+        ctx.save_for_backward(weight, u)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, u = ctx.saved_tensors
+        B = u.shape[0]
+        du = dw = None
+        if ctx.needs_input_grad[1]:
+            du = torch.empty_like(u)
+            for b in range(B):
+                torch.mm(g[b].t(), weight, out=du[b])              # (L, C) x (C, D), g[b].t() read as a transposed operand
+        if ctx.needs_input_grad[0]:
+            dw = torch.mm(g[0], u[0])                              # (C, L) x (L, D)
+            for b in range(1, B):
+                dw.addmm_(g[b], u[b])
+        return dw, du
+
+
+class _ProjectOut(torch.autograd.Function):
+    """(B, D, L) -> (B, L, C) = y[b]^T W^T + bias: one 2-D GEMM per batch row reading y[b].t() as its transposed operand"""
+
+    @staticmethod
+    def forward(ctx, weight, bias, y):
+        B, _, L = y.shape
+        out = torch.empty(B, L, weight.shape[0], dtype=y.dtype, device=y.device)
+        wt = weight.t()
+        for b in range(B):
+            if bias is None:
+                torch.mm(y[b].t(), wt, out=out[b])
+            else:
+                torch.addmm(bias, y[b].t(), wt, out=out[b])
+        ctx.save_for_backward(weight, y)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, y = ctx.saved_tensors
+        B = y.shape[0]
+        dw = db = dy = None
+        if ctx.needs_input_grad[2]:
+            dy = torch.empty_like(y)
+            wt = weight.t()
+            for b in range(B):
+                torch.mm(wt, g[b].t(), out=dy[b])                  # (D, C) x (C, L)
+        if ctx.needs_input_grad[0]:
+            dw = torch.mm(g[0].t(), y[0].t())                      # (C, L) x (L, D)
+            for b in range(1, B):
+                dw.addmm_(g[b].t(), y[b].t())
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = g.sum(dim=(0, 1))
+        return dw, db, dy
+
+
+def project_in(weight, u, bias=None):
+    """in-projection of a (B, L, D) activation straight into the channels-first layout the convolutions read:
+    (C, D) x (B, L, D) -> (B, C, L), one plain 2-D GEMM per batch row on the transposed view u[b].t(), written into its slice of
+    the output (forward and backward: _ProjectIn).  The reference callers write `self.in_proj.weight @ u.transpose(-1, -2)`
+    (hyenadna_flashfftconv.py:269-270, monarch_mixer_sequence_mixer_flashfftconv.py:124-125, bias dropped there too):
+    torch.matmul folds that into a (B*L, D) x (D, C) GEMM and then copies the result into (B, C, L) with a strided elementwise
+    kernel -- 224 of its 267 us at B2 L32K D256 on MI355X, 15 % of a HyenaDNA layer (benchmarks/scratch/proj_probe.py).
+    (Not torch.bmm on the broadcast weight: on this ROCm 7.0 / PyTorch 2.10 stack the BATCHED GEMM with a transposed-view
+    operand writes out of bounds at D = 768, L >= 8192 -- hipBLASLt and rocBLAS alike, the reference's own matmul form included;
+    benchmarks/scratch/bmm_fault2.py.  The 2-D GEMM is the path every nn.Linear takes.)"""
+    if u.shape[0] > _LOOP_MAX_BATCH:      # many short sequences: one GEMM + the layout copy, which is small there
+        out = torch.nn.functional.linear(u, weight).transpose(-1, -2).contiguous()
+    else:
+        out = _ProjectIn.apply(weight, u)
+    return out if bias is None else out + bias.view(1, -1, 1)
 
 
 def project_out(weight, bias, y):
     """out-projection of a channels-first (B, D, L) result back to (B, L, C): nn.Linear on y.transpose(-1, -2) first copies
     the transposed view (55 of 88 us at the shape above); a 2-D GEMM per batch row reads y[b].t() as its transposed operand."""
-    B, _, L = y.shape
-    if B > _LOOP_MAX_BATCH:
+    if y.shape[0] > _LOOP_MAX_BATCH:
         return torch.nn.functional.linear(y.transpose(-1, -2), weight, bias)
-    wt = weight.t()
-    if torch.is_grad_enabled() and (y.requires_grad or weight.requires_grad):
-        rows = [torch.mm(y[b].t(), wt) if bias is None else torch.addmm(bias, y[b].t(), wt) for b in range(B)]
-        return torch.stack(rows)
-    out = torch.empty(B, L, weight.shape[0], dtype=y.dtype, device=y.device)
-    for b in range(B):
-        if bias is None:
-            torch.mm(y[b].t(), wt, out=out[b])
-        else:
-            torch.addmm(bias, y[b].t(), wt, out=out[b])
-    return out
+    return _ProjectOut.apply(weight, bias, y)
 
 
 class FlashHyenaMixer(torch.nn.Module):

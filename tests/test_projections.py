@@ -1,0 +1,26 @@
+"""project_in / project_out (flashfftconv/hyena.py): pure-torch GEMM forms of the projections around the Hyena operator; CPU check
+of values and gradients against the reference callers' forms (hyenadna_flashfftconv.py:269-270, :286-288)."""
+import os, sys
+import pytest
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flash-fft-conv_amd"))
+
+
+@pytest.mark.parametrize("B", [1, 3, 20])      # 20 > the per-row loop limit: the one-GEMM + copy form
+def test_projections_match_the_reference_forms(B):
+    from flashfftconv.hyena import project_in, project_out
+    torch.manual_seed(B)
+    L, D = 40, 16
+    W = torch.randn(3 * D, D, dtype=torch.float64, requires_grad=True); u = torch.randn(B, L, D, dtype=torch.float64, requires_grad=True)
+    Wo = torch.randn(D, D, dtype=torch.float64, requires_grad=True); bo = torch.randn(D, dtype=torch.float64, requires_grad=True)
+    y = torch.randn(B, D, L, dtype=torch.float64, requires_grad=True)
+    a, ar = project_in(W, u), W @ u.transpose(-1, -2)
+    o, orf = project_out(Wo, bo, y), torch.nn.functional.linear(y.transpose(-1, -2), Wo, bo)
+    assert a.shape == (B, 3 * D, L) and a.is_contiguous() and o.shape == (B, L, D) and o.is_contiguous()
+    assert torch.allclose(a, ar, atol=1e-12) and torch.allclose(o, orf, atol=1e-12)
+    ga, go = torch.randn_like(a), torch.randn_like(o)
+    g = torch.autograd.grad([a, o], [W, u, Wo, bo, y], [ga, go])
+    gr = torch.autograd.grad([ar, orf], [W, u, Wo, bo, y], [ga, go])
+    for x, z in zip(g, gr):
+        assert torch.allclose(x, z, atol=1e-10)
+    assert torch.allclose(project_out(Wo, None, y), y.transpose(-1, -2) @ Wo.t(), atol=1e-12)
