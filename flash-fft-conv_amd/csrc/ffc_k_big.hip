@@ -74,3 +74,42 @@ extern "C" int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int di
   if (bf) return dir ? launch_big<32, DT_BF16, true>(a, st) : launch_big<32, DT_BF16, false>(a, st);
   return dir ? launch_big<32, DT_F16, true>(a, st) : launch_big<32, DT_F16, false>(a, st);
 }
+
+// ---- all R passes of a factor R * 32 in one launch (BigBody::run_all): the forward reads the long side once instead of R times,
+// the inverse sums the passes in its fp32 accumulators and writes the long side once (no read-modify-write between launches)
+template <int DT, bool FWD>
+__global__ __launch_bounds__(GeoBig<32>::WGW * 64, 2) void big_all_kernel(BigArgs a) {
+  BigBody<DevB, 32, DT>::template run_all<FWD>(a, blockIdx.x);
+}
+template <int DT, bool FWD>
+static int launch_big_all(const BigArgs& a, hipStream_t st) {
+  int rc = ffc_set_lds(big_all_kernel<DT, FWD>, GeoBig<32>::EBYTES);
+  if (rc) return rc;
+  const int64_t nwg = (int64_t)a.npair * a.Hin * (a.Mi / GeoBig<32>::Mi);
+  if (nwg <= 0 || nwg > 2147483647LL) return ffc_fail("outer pass: bad grid");
+  hipLaunchKernelGGL((big_all_kernel<DT, FWD>), dim3((unsigned)nwg), dim3(GeoBig<32>::WGW * 64), GeoBig<32>::EBYTES, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : ffc_fail(std::string("big_all_kernel launch: ") + hipGetErrorString(e));
+}
+// Same level as the R calls ffc_outer_pass_r(plan_r, c = 0 .. R-1, ...), in one launch.
+extern "C" int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, const void* in, void* out, const void* gate,
+                                  int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream) {
+  const ffc_plan* p = plan_r;
+  if (!p || !in || !out) return ffc_fail("null arg");
+  if (p->hp.N1 != 32 || p->hp.R < 2 || p->hp.R > 4) return ffc_fail("outer pass (R passes): needs a multi-pass plan with a 32-point outer digit");
+  if (Mi % GeoBig<32>::Mi) return ffc_fail("outer pass: Mi must be a multiple of the column block");
+  if (Llong <= 0 || Llong > 32 * Mi) return ffc_fail("outer pass (R passes): the long side must fit the first 32 rows (L <= N / R)");
+  BigArgs a{};
+  a.in = in; a.out = out; a.gate = gate;
+  const bool bf = dtype == DT_BF16;
+  if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
+  for (int c = 0; c < p->hp.R; c++)
+    a.fmats[c] = (bf ? p->d_blob_bf : p->d_blob) + (bf ? p->hp_bf.tabs.matk[c][dir ? 0 : 1] : p->hp.tabs.matk[c][dir ? 0 : 1]);
+  a.fmat = a.fmats[0];
+  a.Bp_valid = (int)Bv; a.npair = (int)npair; a.Hin = (int)Hin; a.Mi = (int)Mi; a.Llong = (int)Llong; a.scale = scale;
+  a.fast = (Llong % 8 == 0) && !(((uintptr_t)in | (uintptr_t)out | (uintptr_t)gate) & 15);
+  a.R = p->hp.R; a.c = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (bf) return dir ? launch_big_all<DT_BF16, true>(a, st) : launch_big_all<DT_BF16, false>(a, st);
+  return dir ? launch_big_all<DT_F16, true>(a, st) : launch_big_all<DT_F16, false>(a, st);
+}

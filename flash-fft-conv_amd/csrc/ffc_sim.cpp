@@ -521,6 +521,29 @@ int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in,
   return 0;
 }
 
+// all R passes in one workgroup run (ffc_outer_pass_all, BigBody::run_all)
+int ffcsim_big_outer_all(int R, int dtype, int fwd, const void* in, void* out, const void* gate, int Bp_valid, int npair,
+                         int Hin, int Mi, int Llong, float scale) {
+  HostPlan p;
+  if (R < 2 || R > 4 || !build_plan(32768 * R, dtype, &p)) return -1;
+  BigArgs a{};
+  a.R = R; a.c = 0;
+  a.in = in; a.out = out; a.gate = gate;
+  for (int c = 0; c < R; c++) a.fmats[c] = p.blob.data() + p.tabs.matk[c][fwd ? 0 : 1];
+  a.fmat = a.fmats[0];
+  a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
+  a.fast = (Llong % 8 == 0) && !g_force_slow;
+  if (Mi % GeoBig<32>::Mi) return -2;
+  const int nwg = npair * Hin * (Mi / GeoBig<32>::Mi);
+  for (int wg = 0; wg < nwg; wg++) {
+#define FFC_BIGA(DD, FF) run_wg(GeoBig<32>::WGW, GeoBig<32>::LDS_BYTES, [&]() { BigBody<SimB, 32, DD>::template run_all<FF>(a, wg); })
+    if (dtype == DT_BF16) { if (fwd) FFC_BIGA(DT_BF16, true); else FFC_BIGA(DT_BF16, false); }
+    else { if (fwd) FFC_BIGA(DT_F16, true); else FFC_BIGA(DT_F16, false); }
+#undef FFC_BIGA
+  }
+  return 0;
+}
+
 int ffcsim_upw(int N) { int u = 0; dispatch<UpwGet>(N, 0, &u); return u; }
 
 int ffcsim_kernel_fft_c(int N, int dtype, const void* xpair, int H, void* kf, float scale) {

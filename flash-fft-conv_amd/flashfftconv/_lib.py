@@ -45,6 +45,7 @@ def lib():
         c_f = ctypes.c_float
         L.ffc_outer_pass.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_vp]
         L.ffc_outer_pass_r.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_vp]
+        L.ffc_outer_pass_all.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_f, c_vp]
         L.ffc_kernel_fft_c.argtypes = [c_vp, c_vp, c_i64, c_vp, c_f, c_vp]
         L.ffc_kernel_ifft_grad_c.argtypes = [c_vp, c_vp, c_i64, c_i64, c_vp, c_f, c_vp]
         L.ffc_kernel_ifft_grad_c_slabs.argtypes = [c_vp, c_vp, c_i64, c_i64, c_vp, c_f, c_vp]

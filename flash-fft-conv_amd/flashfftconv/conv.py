@@ -153,6 +153,9 @@ def _kernel_fft(plan, k):
     return kf
 
 
+_ONE_LAUNCH_LEVEL = _os.environ.get("FFC_BIG_ONE_LAUNCH", "1") != "0"      # A/B switch: "0" = one launch per pass (ffc_outer_pass_r)
+
+
 class _TorchOps:
     """GPU backend of flashfftconv.bigfft (FFT sizes >= 65536): thin wrappers over the C-ABI."""
     BF16 = torch.bfloat16
@@ -172,6 +175,10 @@ class _TorchOps:
         if n0 in (64, 128):
             R = n0 // 32
             pr = self._plan(32768 * R)      # the R-pass plan: its per-pass outer-digit tables are the matrices of the passes
+            if _ONE_LAUNCH_LEVEL:       # all R passes in one launch (long side read / written once)
+                _lib.check(_lib.lib().ffc_outer_pass_all(pr.handle, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
+                                                         npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_all")
+                return
             for c in range(R):
                 _lib.check(_lib.lib().ffc_outer_pass_r(pr.handle, c, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
                                                        npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_r")

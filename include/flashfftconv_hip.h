@@ -133,6 +133,10 @@ int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int d
  * order (c > 0 adds its -- gated -- contribution to the long side). */
 int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int dir, const void* in, void* out, const void* gate, int64_t Bv,
                      int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream);
+/* The same level as the R calls ffc_outer_pass_r(plan_r, c = 0 .. R-1, ...) in ONE launch: the forward reads the long side once
+ * (not R times), the inverse sums the passes in fp32 and writes the long side once (no read-modify-write between launches). */
+int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, const void* in, void* out, const void* gate, int64_t Bv,
+                       int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream);
 int ffc_kernel_fft_c(const ffc_plan* plan, const void* xpair, int64_t H, void* kf_out, float scale, void* stream);
 int ffc_kernel_ifft_grad_c(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream);
 /* ... from `nslab` caller-owned fp32 slabs [nslab][H][kf_elems][2] (multi-GPU B-shard: rows reduce-scattered over the ranks) */

@@ -123,8 +123,13 @@ class SimOps:
         return np.zeros((Bp, Hx, n), np.uint16)
 
     HAS_128 = True
+    one_launch = True
 
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+        if n0 in (64, 128) and self.one_launch:      # all R passes in one workgroup run (ffc_outer_pass_all)
+            rc = lib().ffcsim_big_outer_all(n0 // 32, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale))
+            assert rc == 0, rc
+            return
         if n0 in (64, 128):        # factor R * 32 = R passes of the 32-point kernel (ffc_outer_pass_r)
             for c in range(n0 // 32):
                 rc = lib().ffcsim_big_outer_r(32, n0 // 32, c, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong,

@@ -23,7 +23,8 @@ def test_script(script, done):
                                        # round 3: the recomputing backward (reference memory footprint) at one size of every kind, and
                                        # the two-level 4M / 2-pass-inner 2M forms (L = N/2 runs them anyway at 4M; N/4 cases are forced)
                                        ({"FFC_SAVE_SPECTRUM": "0"}, ["4096", "32768", "65536", "262144", "2097152"]),
-                                       ({"FFC_BIG_ONE128": "0"}, ["2097152", "4194304"])])
+                                       ({"FFC_BIG_ONE128": "0"}, ["2097152", "4194304"]),
+                                       ({"FFC_BIG_ONE_LAUNCH": "0"}, ["2097152", "4194304"])])
 def test_alternative_factorisations_stay_correct(env, sizes):
     """the round-1 paths and the measured-slower factorisations stay reachable through environment switches (A/B runs):
     forward + every gradient against the torch.fft oracle (benchmarks/alt_paths_check.py)"""

@@ -212,6 +212,9 @@ def test_one_level_of_128(L, B, gated, f):
     kf = BG.kernel_fft(ops, dt, N, k, H, L, fac)
     x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None, fac)
     assert x.shape == (2 * ((B + 1) // 2), H * f, M)
+    # one launch for all passes (ffc_outer_pass_all) == one launch per pass (ffc_outer_pass_r): the forward bit for bit
+    per_pass = S.SimOps(); per_pass.one_launch = False
+    assert np.array_equal(x, BG.levels_forward(per_pass, dt, N, ub, B, H, L, g1b if gated else None, fac))
     y = ops.conv(dt, M, x, kf, False)
     out = np.zeros_like(ub)
     BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None, None, fac)
