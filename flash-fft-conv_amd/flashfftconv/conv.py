@@ -39,6 +39,26 @@ def _periodise_k(k, n):
     return torch.cat((k, k), dim=-1)
 
 
+# autograd.Function.forward always runs with grad mode off, and ctx.needs_input_grad mirrors the inputs' requires_grad flags
+# whether or not a graph is being recorded: the caller's grad mode is noted around .apply so that a forward under
+# torch.no_grad() does not store spectra nobody will read
+_TLS = threading.local()
+
+
+def _apply_noting_grad_mode(fn, *args):
+    prev = getattr(_TLS, "grad", None)
+    _TLS.grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _TLS.grad = prev
+
+
+def _recording():
+    g = getattr(_TLS, "grad", None)
+    return True if g is None else g
+
+
 def _kf_key(k):
     return (k.data_ptr(), k._version, tuple(k.shape), k.dtype, k.device)
 
@@ -361,7 +381,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
         ctx.big = mod._big
         kept = None
         if ctx.big:
-            keep = mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+            keep = mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
             # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
             ctx.fac = fac = _big.choose(mod.seqlen, max(u.shape[-1], k.shape[-1]), _TorchOps)
             try:
@@ -389,7 +409,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             rows = _sparse_rows(mod, plan)      # low-pass k_f: the forward kernel that skips the all-zero spectrum rows
             if rows:
                 out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
-            elif mod.training and mod.save_spectrum and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
+            elif mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
                 z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated)
                 if z is not None and ctx.gated:
                     try:
@@ -541,4 +561,4 @@ class FlashFFTConv(torch.nn.Module):
     def forward(self, u, k, pregate=None, postgate=None):
         if pregate is not None or postgate is not None:
             assert pregate is not None and postgate is not None
-        return _FlashFFTConvFn.apply(u, k, self, pregate, postgate)
+        return _apply_noting_grad_mode(_FlashFFTConvFn, u, k, self, pregate, postgate)

@@ -16,7 +16,7 @@ convolution's own backward).  y = x2 * conv(x1 * v, k): the same function as the
 import torch
 
 from . import _lib
-from .conv import FlashFFTConv, _check_inputs, _kernel_fft, _periodise_k, _spectrum_buffer, _kf_key
+from .conv import FlashFFTConv, _check_inputs, _kernel_fft, _periodise_k, _spectrum_buffer, _kf_key, _apply_noting_grad_mode, _recording
 from .depthwise_1d import FlashDepthWiseConv1d
 
 
@@ -42,7 +42,7 @@ class _GatedSlicesFn(torch.autograd.Function):
             sb = D3 * L
             # training: keep the spectra FFT(x1 * v) and the output before the x2 multiply (FlashFFTConv.save_spectrum)
             z = yraw = None
-            if mod.training and mod.save_spectrum and any(ctx.needs_input_grad[:2]):
+            if mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[:2]):
                 z = _spectrum_buffer(plan, B, D, uc.device)
                 if z is not None:
                     try:
@@ -114,7 +114,7 @@ def gated_conv_from_slices(conv, uc, k):
         x1, x2, v = (t.contiguous() for t in uc.split(D, dim=1))
         return conv(v, k, x1, x2)
     _check_inputs(conv, uc[:, :D], k, ())
-    return _GatedSlicesFn.apply(uc, k, conv)
+    return _apply_noting_grad_mode(_GatedSlicesFn, uc, k, conv)
 
 
 class FlashHyenaOp(torch.nn.Module):

@@ -211,7 +211,7 @@ class _BigOps:
 
 class _BShardFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, k, pre, post, ops, group, training):
+    def forward(ctx, u, k, pre, post, ops, group, training, keep=True):
         H, Lk = k.shape
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         s, e = head_range(H, rank, world)
@@ -222,7 +222,7 @@ class _BShardFn(torch.autograd.Function):
         pre = None if pre is None else pre.contiguous()
         post = None if post is None else post.contiguous()
         kept = None
-        if training and hasattr(ops, "conv_keep"):
+        if training and keep and hasattr(ops, "conv_keep"):
             out, kept = ops.conv_keep(u, kf, pre, post)
         else:
             out = ops.conv(u, kf, pre, post)
@@ -257,7 +257,7 @@ class _BShardFn(torch.autograd.Function):
             dkf_local = _reduce_scatter_heads(dkf.contiguous().view((H, rows) + tuple(dkf.shape[1:])), 0, ctx.group)
             dk_local = ctx.ops.dk_from_dkf(dkf_local.reshape((-1,) + tuple(dkf.shape[1:])), ctx.Lk)
             dk = _all_gather_uneven(dk_local, H, 0, ctx.group)        # replicated parameter -> full gradient everywhere
-        return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None
+        return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None, None
 
 
 class _AllReduceGrad(torch.autograd.Function):
@@ -297,9 +297,10 @@ class BatchShardedFFTConv(torch.nn.Module):
             return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
         ops = self._ops if self._ops is not None else (_BigOps if self.conv._big else _HipOps)(self.conv, u.device)
         training = self.conv.training if hasattr(self.conv, "training") else True
+        keep = training and torch.is_grad_enabled()      # spectra are only worth storing when a graph is being recorded
         if self._ops is None:
             from .conv import _check_inputs
             _check_inputs(self.conv, u, k, (pregate, postgate))
             with torch.cuda.device(u.device):
-                return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training)
-        return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training)
+                return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep)
+        return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep)

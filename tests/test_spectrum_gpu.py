@@ -158,3 +158,28 @@ def test_training_step_captures_into_a_hip_graph():
     u.grad.zero_(); k.grad.zero_()
     g.replay(); torch.cuda.synchronize()
     assert torch.equal(u.grad, du0) and torch.equal(k.grad, dk0)
+
+
+@pytest.mark.gpu
+def test_no_spectra_are_stored_without_a_graph():
+    """autograd.Function.forward sees grad mode off and needs_input_grad = the inputs' requires_grad flags either way: the module
+    notes the caller's grad mode, so a forward under torch.no_grad() (training mode, inputs that require grad) allocates no
+    spectrum buffer"""
+    from flashfftconv import FlashFFTConv, conv as C
+    N, B, H, L = 8192, 4, 16, 4096
+    u = torch.randn(B, H, L, device="cuda").bfloat16().requires_grad_(True)
+    k = torch.randn(H, L, device="cuda").requires_grad_(True)
+    mod = FlashFFTConv(N, dtype=torch.bfloat16).cuda()
+    calls = []
+    orig = C._spectrum_buffer
+    C._spectrum_buffer = lambda *a, **kw: (calls.append(1), orig(*a, **kw))[1]
+    try:
+        with torch.no_grad():
+            y0 = mod(u, k)
+        assert not calls
+        y1 = mod(u, k)
+        assert calls and torch.equal(y0, y1)
+        y1.sum().backward()
+        assert u.grad is not None and k.grad is not None
+    finally:
+        C._spectrum_buffer = orig
