@@ -580,7 +580,7 @@ struct Body {
       }
     }
   }
-  // rows_out of pass k0: y[n0 M + m] (+)= i^q y_k0[m] (* postgate), q = n0 k0 4/R: i^q (r + i s) = (r,s), (-s,r), (-r,-s),
+  // rows_out of pass k0: y[n0 M + m] (+)= i^q y_k0[m], the last pass (* postgate), q = n0 k0 4/R: i^q (r + i s) = (r,s), (-s,r), (-r,-s),
   // (s,-r).  Passes k0 > 0 add to what the SAME wave stored in the earlier passes (its own column slice).
   template <int NC>
   static FFC_FN void rows_out_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
@@ -630,8 +630,10 @@ struct Body {
           // plane 0: {r, -s, -r, s}[q], plane 1: {s, r, -s, -r}[q]
           U4 c = ((q & 1) != 0) == (pl == 0) ? y[1] : y[0];
           const float sg = pl == 0 ? ((q == 0 || q == 3) ? 1.0f : -1.0f) : (q < 2 ? 1.0f : -1.0f);
-          if (a.postgate) c = mul4(c, gload8((const uint16_t*)a.postgate + rg[pl], n, a.L, fast, okb[pl]));
+          // the passes' contributions are summed ungated; the output gate multiplies the sum, on the last pass only (the gate
+          // load and its 28 VALU per 8 elements were 20 % of a pass's VALU count when every pass multiplied its own part)
           if (ps.k0 > 0) c = add4(HOIST ? old.v[HOIST ? i : 0][pl] : gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]), c, sg);
+          if (a.postgate && ps.k0 == ps.R - 1) c = mul4(c, gload8((const uint16_t*)a.postgate + rg[pl], n, a.L, fast, okb[pl]));
           gstore8((uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl], c);
         }
       }
