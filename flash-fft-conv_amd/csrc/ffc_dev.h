@@ -365,9 +365,9 @@ static int ffc_dispatch(int N, int dtype, A&&... args) {
 
 // pairs per chunk / number of chunks so the grid fills the chip (>= ~2 waves of workgroups) while a
 // workgroup still loops over several pairs of one head (k_f[h] reuse through L2).
-// fp32 dk_f partial-sum slabs per chunk: geometries with an outer stage reduce their units inside the workgroup
-// (Modes::w_acc_finish) and write one slab; the single-tile geometries (N <= 1024) write one per unit.
-static inline int ffc_slabs_per_chunk(const ffc_plan* p) { return p->hp.N1 > 1 ? 1 : 8 / p->hp.NW; }
+// fp32 dk_f partial-sum slabs per chunk: every geometry reduces its units inside the workgroup (Modes::w_acc_finish,
+// Modes::reduce_store_w) and writes one slab.
+static inline int ffc_slabs_per_chunk(const ffc_plan* p) { (void)p; return 1; }
 
 static inline void* ffc_zscratch(const ffc_plan* p, void* ws, int H, int nchunk);
 static inline void ffc_choose_chunks(const ffc_plan* p, int H, int npair, int* nchunk, int* ppc, bool fwd_only = false) {

@@ -612,7 +612,7 @@ struct Modes : Body<B, GEO, DT> {
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
     // Multi-pass sizes: slab rows are (head, pass).
     float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
-                     : d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+                     : d.ws + ((int64_t)chunk * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -688,7 +688,7 @@ struct Modes : Body<B, GEO, DT> {
               B::lds_fence();
             }
           }
-          store_w(d.ws + ((((int64_t)chunk * GEO::UPW + u) * a.H + h) * a.R + k0) * 2048, wre, wim);
+          reduce_store_w(d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * 2048, u, wre, wim);
         }
       }
     } else {
@@ -722,7 +722,7 @@ struct Modes : Body<B, GEO, DT> {
           B::lds_fence();
         }
       }
-      store_w(slab, wre, wim);
+      reduce_store_w(slab, u, wre, wim);
     }
   }
   // ------------------------------------------------------------------ fused backward
@@ -796,7 +796,7 @@ struct Modes : Body<B, GEO, DT> {
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
     // Multi-pass sizes: slab rows are (head, pass).
     float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
-                     : d.ws + ((int64_t)(GEO::OUTER ? chunk : chunk * GEO::UPW + u) * a.H + h) * (GEO::NT * 2048);
+                     : d.ws + ((int64_t)chunk * a.H + h) * (GEO::NT * 2048);
     InnerRegs R;
     if constexpr (GEO::OUTER) {
       const int iters = (p1 - p0 + GEO::UPW - 1) / GEO::UPW;
@@ -1011,7 +1011,7 @@ struct Modes : Body<B, GEO, DT> {
               B::lds_fence();
             }
           }
-          store_w(d.ws + ((((int64_t)chunk * GEO::UPW + u) * a.H + h) * a.R + k0) * 2048, wre, wim);
+          reduce_store_w(d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * 2048, u, wre, wim);
         }
       }
     } else {
@@ -1051,7 +1051,7 @@ struct Modes : Body<B, GEO, DT> {
           B::lds_fence();
         }
       }
-      store_w(slab, wre, wim);
+      reduce_store_w(slab, u, wre, wim);
     }
   }
 
@@ -1078,6 +1078,40 @@ struct Modes : Body<B, GEO, DT> {
         wre[r] = wre[r] + (re[r] * ur + im[r] * ui);
         wim[r] = wim[r] + (im[r] * ur - re[r] * ui);
       }
+    }
+  }
+  // Single-tile sizes: the eight units' sums of a (head, chunk[, pass]) job are added up through LDS -- the units' exchange
+  // buffers, 8 x 4 KB, free between two jobs -- and leave as ONE slab.  (Round 2 wrote one slab per unit: 8x the partial-sum
+  // traffic and a serial 8-slab loop in dkifft, 30 us at fft 256 against 22 us for the backward kernel itself.)
+  // Wave u ends up with accumulator registers 2u, 2u+1 of every lane = one 16-byte store of store_w's layout.
+  static FFC_FN void reduce_store_w(float* slab, int u, const A16& wre, const A16& wim) {
+    static_assert(!GEO::OUTER, "single-tile geometries");
+    if constexpr (GEO::UPW == 1) {
+      store_w(slab, wre, wim);
+    } else {
+      static_assert(GEO::UPW == 8 && GEO::UPW * GEO::EBYTES >= 8 * 4096, "one wave per unit, 4 KB of exchange buffer each");
+      const i32 lane = B::opaque(B::lane());
+      f32 sr[2], si[2];
+#pragma unroll
+      for (int plane = 0; plane < 2; plane++) {
+        B::barrier();                 // every unit is done with its exchange buffer (plane 1: with the sums of plane 0)
+#pragma unroll
+        for (int r = 0; r < 16; r++) B::lds_w32(((u * 16 + r) * 64 + lane) * 4, B::as_u32(plane ? wim[r] : wre[r]));
+        B::barrier();
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          f32 acc = B::fconst(0.f);
+#pragma unroll
+          for (int v = 0; v < 8; v++) acc = acc + B::as_f32(B::lds_r32(((v * 16 + (2 * u + k)) * 64 + lane) * 4));
+          if (plane) si[k] = acc; else sr[k] = acc;
+        }
+      }
+      B::barrier();                   // the next job's rows may overwrite the buffers
+      const i32 c = lane & 31, hi = lane >> 5;
+      const i32 idx = ((hi + 2 * (u >> 1)) * 32 + c) * 2 + (u & 1);
+      U4 n;
+      n.x = B::as_u32(sr[0]); n.y = B::as_u32(si[0]); n.z = B::as_u32(sr[1]); n.w = B::as_u32(si[1]);
+      B::g_w128(slab, idx, n, B::ptrue());
     }
   }
   static FFC_FN void store_w(float* slab, const A16& re, const A16& im) {

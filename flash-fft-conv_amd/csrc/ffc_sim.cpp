@@ -589,7 +589,7 @@ int ffcsim_conv_bwd_dkf(int N, int dtype, const void* dout, const void* u, const
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
   int rc = dispatch<DkfRun>(N, dtype, d);
-  return rc < 0 ? rc : a.nchunk * (p.N1 > 1 ? 1 : upw);   // number of slabs written
+  return rc < 0 ? rc : a.nchunk;   // number of slabs written (one per chunk)
 }
 
 // fused backward: du (and dpre if non-null) + dk_f slabs; returns the number of slabs
@@ -614,7 +614,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
   int rc = dispatch<BwdRun>(N, dtype, d);
-  return rc < 0 ? rc : a.nchunk * (p.N1 > 1 ? 1 : upw);
+  return rc < 0 ? rc : a.nchunk;
 }
 
 int ffcsim_kernel_ifft_grad_c(int N, const float* ws, int nslab, int H, void* outpair, float scale) {
