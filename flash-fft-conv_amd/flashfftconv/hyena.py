@@ -145,10 +145,12 @@ class _ProjectIn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, u):
         B, L, _ = u.shape
-        out = torch.empty(B, weight.shape[0], L, dtype=u.dtype, device=u.device)
+        w = weight if weight.dtype == u.dtype else weight.to(u.dtype)      # fp32 master weights under mixed precision
+        out = torch.empty(B, w.shape[0], L, dtype=u.dtype, device=u.device)
         for b in range(B):
-            torch.mm(weight, u[b].t(), out=out[b])
-        ctx.save_for_backward(weight, u)
+            torch.mm(w, u[b].t(), out=out[b])
+        ctx.save_for_backward(w, u)
+        ctx.w_dtype = weight.dtype
         return out
 
     @staticmethod
@@ -164,6 +166,7 @@ class _ProjectIn(torch.autograd.Function):
             dw = torch.mm(g[0], u[0])                              # (C, L) x (L, D)
             for b in range(1, B):
                 dw.addmm_(g[b], u[b])
+            dw = dw.to(ctx.w_dtype)
         return dw, du
 
 
@@ -173,15 +176,18 @@ class _ProjectOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, y):
         B, _, L = y.shape
-        out = torch.empty(B, L, weight.shape[0], dtype=y.dtype, device=y.device)
-        wt = weight.t()
+        w = weight if weight.dtype == y.dtype else weight.to(y.dtype)      # fp32 master weights under mixed precision
+        bb = bias if bias is None or bias.dtype == y.dtype else bias.to(y.dtype)
+        out = torch.empty(B, L, w.shape[0], dtype=y.dtype, device=y.device)
+        wt = w.t()
         for b in range(B):
-            if bias is None:
+            if bb is None:
                 torch.mm(y[b].t(), wt, out=out[b])
             else:
-                torch.addmm(bias, y[b].t(), wt, out=out[b])
-        ctx.save_for_backward(weight, y)
+                torch.addmm(bb, y[b].t(), wt, out=out[b])
+        ctx.save_for_backward(w, y)
         ctx.has_bias = bias is not None
+        ctx.w_dtype, ctx.b_dtype = weight.dtype, (None if bias is None else bias.dtype)
         return out
 
     @staticmethod
@@ -198,8 +204,9 @@ class _ProjectOut(torch.autograd.Function):
             dw = torch.mm(g[0].t(), y[0].t())                      # (C, L) x (L, D)
             for b in range(1, B):
                 dw.addmm_(g[b].t(), y[b].t())
+            dw = dw.to(ctx.w_dtype)
         if ctx.has_bias and ctx.needs_input_grad[1]:
-            db = g.sum(dim=(0, 1))
+            db = g.sum(dim=(0, 1)).to(ctx.b_dtype)
         return dw, db, dy
 
 

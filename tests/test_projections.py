@@ -24,3 +24,18 @@ def test_projections_match_the_reference_forms(B):
     for x, z in zip(g, gr):
         assert torch.allclose(x, z, atol=1e-10)
     assert torch.allclose(project_out(Wo, None, y), y.transpose(-1, -2) @ Wo.t(), atol=1e-12)
+
+
+def test_projections_take_fp32_master_weights():
+    """bf16 activations with fp32 weights (mixed-precision training): cast inside, gradients come back in the weights' dtype"""
+    from flashfftconv.hyena import project_in, project_out
+    torch.manual_seed(0)
+    B, L, D = 2, 24, 8
+    W = torch.randn(3 * D, D, requires_grad=True); Wo = torch.randn(D, D, requires_grad=True); bo = torch.randn(D, requires_grad=True)
+    u = torch.randn(B, L, D).bfloat16().requires_grad_(True); y = torch.randn(B, D, L).bfloat16().requires_grad_(True)
+    a = project_in(W, u); o = project_out(Wo, bo, y)
+    assert a.dtype == torch.bfloat16 and o.dtype == torch.bfloat16
+    g = torch.autograd.grad([a, o], [W, u, Wo, bo, y], [torch.ones_like(a), torch.ones_like(o)])
+    assert [t.dtype for t in g] == [torch.float32, torch.bfloat16, torch.float32, torch.float32, torch.bfloat16]
+    ar = (W.bfloat16() @ u.transpose(-1, -2)).float()
+    assert ((a.float() - ar).norm() / ar.norm()).item() < 2e-2
