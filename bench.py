@@ -352,7 +352,7 @@ def main():
         torch.cuda.empty_cache()
         from benchmarks import sweep as SW
         keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "fwd_ms_min", "bwd_ms_min", "fwd_infer_ms", "timing", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
-                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac")
+                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes")
         out["configs"] = [{kk: r[kk] for kk in keep if kk in r} for r in list(SW.config_rows())[1:]]
         out["sweep"] = [{kk: r[kk] for kk in keep if kk in r} for r in SW.sweep_rows()]
         # the reference's published table (gated forward, fp16, L = N, scaled to B=64 x H=768; 1 x H100-SXM, README.md:224-230)

@@ -30,6 +30,61 @@ def ev_time(fn, iters, repeats=REPEATS):
     return ts[len(ts) // 2], ts[0]
 
 
+def peak_bytes(fn):
+    """peak device memory of one call on top of what is allocated before it (inputs, parameters, plan tables):
+    torch.cuda.max_memory_allocated as reference benchmarks/benchmark.py:137-147 measures it, minus the resident base"""
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    fn()
+    torch.cuda.synchronize()
+    return int(torch.cuda.max_memory_allocated() - base)
+
+
+def _torch_fft_conv(u, k, N, g):
+    """the torch.fft form the reference compares its memory against (tests/test_flashfftconv.py:5-13; README.md:232)"""
+    x = u * g[0] if g else u
+    y = torch.fft.ifft(torch.fft.fft(x.float(), n=N) * torch.fft.fft(k.float(), n=N), n=N).real.to(u.dtype)[..., : u.shape[-1]]
+    return y * g[1] if g else y
+
+
+def peak_mem_row(mod, u, k, g, dout, N):
+    """peak memory (bytes above the resident inputs) of: the inference forward; forward + backward with the module default
+    (save_spectrum on: the forward keeps FFT(u) for the backward pass); the same with save_spectrum off (the reference's
+    footprint: inputs only); the torch.fft form.  README.md:232 publishes the ratio torch.fft / FlashFFTConv ("memory savings")."""
+    leaves = [u, k] + list(g)
+
+    def clear():
+        for t in leaves:
+            t.grad = None
+
+    def fb(fn):
+        def run():
+            clear()
+            fn().backward(dout)
+        return run
+    out = {}
+    with torch.no_grad():
+        mod.eval(); out["fwd_infer"] = peak_bytes(lambda: mod(u, k, *g)); mod.train()
+    keep = mod.save_spectrum
+    out["fwd_bwd_save_spectrum"] = peak_bytes(fb(lambda: mod(u, k, *g)))
+    mod.save_spectrum = False
+    out["fwd_bwd_recompute"] = peak_bytes(fb(lambda: mod(u, k, *g)))
+    mod.save_spectrum = keep
+    try:
+        with torch.no_grad():
+            out["fwd_torch_fft"] = peak_bytes(lambda: _torch_fft_conv(u, k, N, g))
+        out["fwd_bwd_torch_fft"] = peak_bytes(fb(lambda: _torch_fft_conv(u, k, N, g)))
+        out["saving_vs_torch_fft_fwd"] = round(out["fwd_torch_fft"] / max(out["fwd_infer"], 1), 2)
+        out["saving_vs_torch_fft_fwd_bwd"] = round(out["fwd_bwd_torch_fft"] / max(out["fwd_bwd_save_spectrum"], 1), 2)
+    except torch.cuda.OutOfMemoryError:
+        out["fwd_bwd_torch_fft"] = None
+    clear()
+    out["inputs_bytes"] = int(sum(t.numel() * t.element_size() for t in leaves) + dout.numel() * dout.element_size())
+    out["how"] = "max_memory_allocated over one call minus memory_allocated before it (bytes; H_run heads, not rescaled)"
+    return out
+
+
 def set_iters(N):
     return 20 if N < 1048576 else 8 if N == 1048576 else 5
 
@@ -58,6 +113,8 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
             t.grad = None          # otherwise autograd adds an accumulate pass over every gradient tensor
         y.backward(dout, retain_graph=True)
     (t_b, t_b_min) = ev_time(bwd, iters)
+    del y
+    pm = peak_mem_row(mod, u, k, g, dout, N)
     scale = H / Hrun
     t_f, t_b, t_fi, t_f_min, t_b_min = t_f * scale, t_b * scale, t_fi * scale, t_f_min * scale, t_b_min * scale
     rows = B * H
@@ -73,7 +130,8 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
                       "seq_per_s": round(rows / ((t_f + t_b) * 1e-3)),
                       "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
                       "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9),
-                      "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4)})
+                      "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4),
+                      "peak_mem_bytes": pm})
 
 
 def conv1d_row():
@@ -144,7 +202,10 @@ def readme_rows(sizes=None):
             (ti, _) = ev_time(lambda: mod(u, k, *g), set_iters(N))
             mod.train()
         adj = 64 * 768 / (B * H)
-        yield {"row": f"README table N={N}", "fft": N, "L": N, "dtype": "float16", "gated": True, "B_run": B, "H_run": H,
+        dout = torch.randn(B, H, N, device="cuda").to(torch.float16)
+        pm = peak_mem_row(mod, u, k, g, dout, N)
+        del dout
+        yield {"row": f"README table N={N}", "peak_mem_bytes": pm, "fft": N, "L": N, "dtype": "float16", "gated": True, "B_run": B, "H_run": H,
                "fwd_ms_scaled_to_B64_H768": round(t * adj, 3), "fwd_ms_min_scaled": round(tmin * adj, 3),
                "fwd_no_grad_ms_scaled": round(ti * adj, 3),
                "h100_ms_published": H100_GATED_FWD_MS[N], "speedup_vs_h100_published": round(H100_GATED_FWD_MS[N] / (t * adj), 2)}

@@ -10,8 +10,8 @@ SIM_SO = os.path.join(LIB, "libffcsim.so")
 # --amdgpu-mfma-vgpr-form: MFMA results stay in architectural VGPRs; the accumulation registers a0..a127 are
 #   addressed by hand in the backward kernels (dk_f partial sums) and must never be picked by the allocator.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-mllvm", "--amdgpu-mfma-vgpr-form", "-fPIC"]
-AGPR_CHECKED = ["ffc_k_dkf.hip", "ffc_k_bwd.hip"]     # translation units whose device code is scanned by check_agpr()
-HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_bwd.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_conv1d_t0.hip", "ffc_conv1d_t1.hip", "ffc_conv1d_t2.hip", "ffc_plan.cpp"]
+AGPR_CHECKED = ["ffc_k_dkf.hip", "ffc_k_bwd.hip", "ffc_k_bwdz.hip"]     # translation units whose device code is scanned by check_agpr()
+HIP_SRCS = ["ffc_hip.hip", "ffc_k_conv.hip", "ffc_k_kfft.hip", "ffc_k_dkf.hip", "ffc_k_bwd.hip", "ffc_k_bwdz.hip", "ffc_k_dk.hip", "ffc_k_big.hip", "ffc_conv1d.hip", "ffc_conv1d_t0.hip", "ffc_conv1d_t1.hip", "ffc_conv1d_t2.hip", "ffc_plan.cpp"]
 SIM_SRCS = ["ffc_sim.cpp", "ffc_plan.cpp"]
 
 

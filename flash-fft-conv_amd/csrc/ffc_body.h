@@ -67,6 +67,13 @@ struct ConvArgs {
   // all-zero spectrum rows (ffc_conv_fwd_sparse; 32-point inner digits only)
   int sparse;
   unsigned long long* prof;  // profiling build only: per-wave phase cycle sums [wg][wave][8]
+  // optional side product of the row load (rows_store / rows_in_rp): aux_out[b,h,n] = u[b,h,n] * aux_in[b,h,n], the raw row
+  // before the pregate multiply.  The gated backward on saved spectra (ffc_conv_bwd_zy) reads dout as `u` here, with
+  // aux_in = the forward output before the postgate multiply: aux_out = dpostgate, from the registers that hold dout anyway
+  // (round 3 ran a torch elementwise kernel for it: 3 x |u| bytes of extra traffic).  Batch strides in elements.
+  const void* aux_in;
+  void* aux_out;
+  int64_t sbai, sbao;
 };
 
 // One pass of a multi-pass size (fft size N = R * M, M = GEO::N = N1 * Mi; HostPlan::R).  With n = n0 M + n1 Mi + mi and
@@ -418,6 +425,19 @@ struct Body {
           v.x = B::sel(ok, v.x, B::uconst(0)); v.y = B::sel(ok, v.y, B::uconst(0));
           v.z = B::sel(ok, v.z, B::uconst(0)); v.w = B::sel(ok, v.w, B::uconst(0));
         }
+        if (a.aux_in && !(GEO::OUTER && fast && ((i * 64) / CPR) * GEO::Mi >= a.L)) {      // side product aux_out = row * aux_in
+          if constexpr (GEO::OUTER) {
+            const int b = 2 * pq + pl;
+            const bool ok = b < a.B;
+            const i32 n = row * GEO::Mi + m;
+            U4 r = gload8((const uint16_t*)a.aux_in + row_off(b, ok, a.sbai, h, a.L), n, a.L, fast, ok);
+            gstore8((uint16_t*)a.aux_out + row_off(b, ok, a.sbao, h, a.L), n, a.L, fast, ok, mul4(v, r));
+          } else {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            U4 r = gload8_rows((const uint16_t*)a.aux_in, b, h, a, a.sbai, m, fast, b < a.B);
+            gstore8_rows((uint16_t*)a.aux_out, b, h, a, a.sbao, m, fast, b < a.B, mul4(v, r));
+          }
+        }
         if (a.pregate && !(GEO::OUTER && fast && ((i * 64) / CPR) * GEO::Mi >= a.L)) {
           U4 g;
           if constexpr (GEO::OUTER) {
@@ -577,6 +597,31 @@ struct Body {
         o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
         o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
         B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+      }
+    }
+  }
+  // Multi-pass sizes: the side product of the row load (ConvArgs::aux_in, see rows_store) as a pass of its own over the wave's
+  // column slice, run once per pair (pass 0) ahead of rows_in_rp, which then finds the rows of `u` in L2.  (Folded into
+  // load_gated it overflowed the 128-VGPR budget of the multi-pass backward kernel; build.py check_agpr.)
+  template <int NC>
+  static FFC_FN void rows_aux_rp(const ConvArgs& a, int h, int pq, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
+    const int n0max = (a.L + GEO::N - 1) / GEO::N;
+#pragma unroll 1
+    for (int n0 = 0; n0 < n0max; n0++) {
+#pragma unroll 1
+      for (int i = 0; i < NC; i++) {
+        i32 idx = lane + i * 64;
+        i32 n = (idx / CPR) * GEO::Mi + (idx % CPR) * 8 + un.wq * 128 * GEO::S1 + n0 * GEO::N;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          const int b = 2 * pq + pl;
+          const bool ok = b < a.B;
+          U4 v = gload8((const uint16_t*)a.u + row_off(b, ok, a.sbu, h, a.L), n, a.L, fast, ok);
+          U4 r = gload8((const uint16_t*)a.aux_in + row_off(b, ok, a.sbai, h, a.L), n, a.L, fast, ok);
+          gstore8((uint16_t*)a.aux_out + row_off(b, ok, a.sbao, h, a.L), n, a.L, fast, ok, mul4(v, r));
+        }
       }
     }
   }

@@ -338,6 +338,8 @@ static inline int ffc_fail(const std::string& m) { ffc_set_error_(m.c_str()); re
 // several GPUs (per-device plan cache in flashfftconv.conv.get_plan) would otherwise launch > 64 KB kernels on its second
 // device with the first device's setting only.
 int ffc_set_lds_once(const void* kernel, int bytes);      // ffc_hip.hip
+namespace ffc { struct DkfArgs; }
+int ffc_bwdz_launch(int N, int dtype, const ffc::DkfArgs& d, hipStream_t st);      // ffc_k_bwdz.hip: fused backward on saved spectra
 template <class K>
 static int ffc_set_lds(K kernel, int bytes) { return ffc_set_lds_once((const void*)kernel, bytes); }
 

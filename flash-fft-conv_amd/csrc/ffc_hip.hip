@@ -46,16 +46,24 @@ static thread_local std::string g_err;
 #include <map>
 #include <mutex>
 int ffc_set_lds_once(const void* kernel, int bytes) {
-  static std::mutex mu;
-  static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> largest size set
+  // fast path in front of the mutex (every small-size launch paid a lock and a map lookup): the last
+  // (kernel, device) pair this thread has seen set
+  static thread_local const void* last_k = nullptr;
+  static thread_local int last_dev = -1, last_bytes = 0;
   int dev = 0;
   (void)hipGetDevice(&dev);
+  if (kernel == last_k && dev == last_dev && bytes <= last_bytes) return 0;
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;      // (kernel, device) -> largest size set
   std::lock_guard<std::mutex> lk(mu);
   auto it = done.find({kernel, dev});
-  if (it != done.end() && it->second >= bytes) return 0;
-  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e != hipSuccess) return ffc_fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-  done[{kernel, dev}] = bytes;
+  if (it == done.end() || it->second < bytes) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return ffc_fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    done[{kernel, dev}] = bytes;
+    it = done.find({kernel, dev});
+  }
+  last_k = kernel; last_dev = dev; last_bytes = it->second;
   return 0;
 }
 #define fail ffc_fail
@@ -74,9 +82,17 @@ __global__ __launch_bounds__(256) void poison_kernel(uint32_t pat, int words, ui
 
 // Measured peaks of the box the process runs on (bench.py `peak_measured`; SURVEY.md section 6 asks for them next to the
 // nominal 8 TB/s / 2.5 PFLOP/s): a 16-byte-per-lane stream copy and a register-resident v_mfma_f32_32x32x16_bf16 loop.
-__global__ void peak_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) dst[i] = src[i];
+// 4 x 16 bytes per lane and iteration, streaming (non-temporal) loads and stores: the lines are touched once
+__global__ __launch_bounds__(256) void peak_copy_kernel(const u32x4v* __restrict__ src, u32x4v* __restrict__ dst, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    u32x4v a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    u32x4v c = __builtin_nontemporal_load(src + i + 2 * stride), e = __builtin_nontemporal_load(src + i + 3 * stride);
+    __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+    __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(e, dst + i + 3 * stride);
+  }
+  for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 __global__ __launch_bounds__(256) void peak_mfma_kernel(float* sink, int iters) {
   const int lane = threadIdx.x & 63;
@@ -100,37 +116,48 @@ int ffc_debug_peaks(double* copy_GBs, double* mfma_TFLOPs) {
   int dev = 0, ncu = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-  const size_t bytes = (size_t)1 << 30;
-  uint4 *s = nullptr, *d = nullptr; float* sink = nullptr;
-  hipEvent_t e0, e1;
-  if (hipMalloc((void**)&s, bytes) != hipSuccess || hipMalloc((void**)&d, bytes) != hipSuccess || hipMalloc((void**)&sink, 64) != hipSuccess ||
-      hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-    if (s) (void)hipFree(s);
-    if (d) (void)hipFree(d);
-    return fail("peak probe: allocation failed");
-  }
-  (void)hipMemset(s, 1, bytes); (void)hipMemset(d, 2, bytes);
+  // 2 GiB each way (well past the 256 MB Infinity Cache), on a stream of its own; everything is released on every path
+  const size_t bytes = (size_t)2 << 30;
+  u32x4v *s = nullptr, *d = nullptr; float* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;
+  bool ok = hipMalloc((void**)&s, bytes) == hipSuccess && hipMalloc((void**)&d, bytes) == hipSuccess &&
+            hipMalloc((void**)&sink, 64) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
   double bc = 0, bm = 0;
-  for (int rep = 0; rep < 6; rep++) {
-    (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(peak_copy_kernel, dim3(ncu * 8), dim3(512), 0, 0, s, d, bytes / 16);
-    (void)hipEventRecord(e1, 0);
-    (void)hipEventSynchronize(e1);
-    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-    if (rep && ms > 0 && 2.0 * bytes / (ms * 1e-3) / 1e9 > bc) bc = 2.0 * bytes / (ms * 1e-3) / 1e9;
+  if (ok) {
+    (void)hipMemsetAsync(s, 1, bytes, st); (void)hipMemsetAsync(d, 2, bytes, st);
+    // grid sweep (workgroups per CU), best of 3 timed launches each after one warm-up
+    const int per_cu[] = {2, 4, 8, 16, 32};
+    for (int g : per_cu) {
+      for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(peak_copy_kernel, dim3(ncu * g), dim3(256), 0, st, s, d, bytes / 16);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms > 0 && 2.0 * bytes / (ms * 1e-3) / 1e9 > bc) bc = 2.0 * bytes / (ms * 1e-3) / 1e9;
+      }
+    }
+    const int iters = 20000;
+    for (int rep = 0; rep < 4; rep++) {
+      (void)hipEventRecord(e0, st);
+      hipLaunchKernelGGL(peak_mfma_kernel, dim3(ncu * 4), dim3(256), 0, st, sink, iters);
+      (void)hipEventRecord(e1, st);
+      (void)hipEventSynchronize(e1);
+      float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+      double fl = (double)ncu * 4 * 4 * iters * 4 * (2.0 * 32 * 32 * 16);
+      if (rep && ms > 0 && fl / (ms * 1e-3) / 1e12 > bm) bm = fl / (ms * 1e-3) / 1e12;
+    }
+    ok = hipGetLastError() == hipSuccess;
   }
-  const int iters = 20000;
-  for (int rep = 0; rep < 4; rep++) {
-    (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(peak_mfma_kernel, dim3(ncu * 4), dim3(256), 0, 0, sink, iters);
-    (void)hipEventRecord(e1, 0);
-    (void)hipEventSynchronize(e1);
-    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-    double fl = (double)ncu * 4 * 4 * iters * 4 * (2.0 * 32 * 32 * 16);
-    if (rep && ms > 0 && fl / (ms * 1e-3) / 1e12 > bm) bm = fl / (ms * 1e-3) / 1e12;
-  }
-  (void)hipFree(s); (void)hipFree(d); (void)hipFree(sink);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (s) (void)hipFree(s);
+  if (d) (void)hipFree(d);
+  if (sink) (void)hipFree(sink);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (!ok) return fail("peak probe: allocation or launch failed");
   *copy_GBs = bc; *mfma_TFLOPs = bm;
   return 0;
 }

@@ -1,99 +1,29 @@
 // Fused backward kernel (Modes::bwd) + ffc_conv_bwd / ffc_conv_bwd_gated(_strided).  (Split from ffc_k_dkf.hip so that the two
 // longest translation units of the library compile side by side.)
-#include "ffc_dev.h"
-using namespace ffc;
+#include "ffc_bwd_launch.h"
 
-template <class GEO, int DT, bool HALF>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_kernel(DkfArgs d) {
-  if constexpr (GEO::NW == 1) {
-    // one wave per unit (fft 4096): persistent workgroups walk the (head, chunk) jobs (see conv_kernel); the waves
-    // only meet at the table copy and at the end-of-chunk reduction of the dk_f sums
-    const int total = ((d.c.H + 7) & ~7) * d.c.nchunk;
-    for (int id = blockIdx.x; id < total; id += gridDim.x) {
-      int h, chunk;
-      if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+// out[b, h, n] = x[b, h, n] * y[b, h, n] on (B, H, L) rows with batch strides (elements), fp32 product rounded once: the
+// dpostgate = dout * y_raw of the multi-pass sizes (fft 65536 / 131072), whose backward kernel has no registers to spare for it
+template <int DT>
+__global__ __launch_bounds__(256) void mul_rows_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ y, uint16_t* __restrict__ out,
+                                                       int64_t HL, int64_t sbx, int64_t sby, int64_t sbo, int fast) {
+  const int b = blockIdx.y;
+  const uint16_t* xb = x + b * sbx; const uint16_t* yb = y + b * sby; uint16_t* ob = out + b * sbo;
+  if (fast) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HL / 8; i += (int64_t)gridDim.x * blockDim.x) {
+      const u32x4v a = __builtin_nontemporal_load((const u32x4v*)xb + i), c = __builtin_nontemporal_load((const u32x4v*)yb + i);
+      u32x4v o;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        o[q] = DevB::pack<DT>(DevB::unpack_lo<DT>(a[q]) * DevB::unpack_lo<DT>(c[q]), DevB::unpack_hi<DT>(a[q]) * DevB::unpack_hi<DT>(c[q]));
+      __builtin_nontemporal_store(o, (u32x4v*)ob + i);
     }
   } else {
-    int h, chunk;
-    if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-    stagger_start(d.c.flags);
-    Modes<DevBO, GEO, DT>::template bwd<HALF>(d, h, chunk, blockIdx.x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HL; i += (int64_t)gridDim.x * blockDim.x)
+      ob[i] = (uint16_t)DevB::pack<DT>(DevB::unpack_lo<DT>(xb[i]) * DevB::unpack_lo<DT>(yb[i]), 0.f);
   }
-}
-// single-tile sizes (fft <= 2048): persistent workgroups (two per CU) walk the (head, chunk) jobs, the plan tables are copied
-// to LDS once per workgroup instead of once per job (a job is one pair per wave at B = 16: the copy was as large as the work)
-template <class GEO, int DT>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel_small(DkfArgs d) {
-  using M = Modes<DevB, GEO, DT>;
-  M::BD::setup_tables(d.c.tab, d.c.t);
-  if constexpr (GEO::N == 1024) { if (d.c.R > 1) M::BD::setup_tables_ipass(d.c.tab, d.c.t, d.c.R); }
-  const int total = ((d.c.H + 7) & ~7) * d.c.nchunk;
-  for (int id = blockIdx.x; id < total; id += gridDim.x) {
-    int h, chunk;
-    if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) M::template bwd<false, false, false>(d, h, chunk, id);
-  }
-}
-template <class GEO, int DT, bool HALF>
-__global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_rp_kernel(DkfArgs d) {
-  int h, chunk;
-  if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
-  const int wv = DevBO::wave(), wg = blockIdx.x;
-#pragma unroll 1
-  for (int k0 = 0; k0 < d.c.R; k0++) Modes<DevBO, GEO, DT>::template bwd<HALF, true>(d, h, chunk, wg, k0, wv);
 }
 
-template <class GEO, int DT>
-struct BwdLaunch {
-  static int run(const DkfArgs& d, hipStream_t st) {
-    int hpad = (d.c.H + 7) & ~7;
-    int ngrid = hpad * d.c.nchunk;
-    if (d.c.R > 1) {
-      if constexpr (GEO::N == 32768) {
-        const dim3 grid(ngrid), block(GEO::WGW * 64);
-        if (16 * GEO::Mi >= d.c.L) {
-          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, true>, GEO::LDS_BYTES);
-          if (rc) return rc;
-          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
-        } else {
-          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, false>, GEO::LDS_BYTES);
-          if (rc) return rc;
-          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
-        }
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_rp_kernel launch: ") + hipGetErrorString(e));
-      } else if constexpr (GEO::OUTER) {
-        return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
-      }
-    }
-    if (GEO::OUTER && GEO::NW == 1 && d.c.persist > 0 && ngrid > d.c.persist) ngrid = d.c.persist;   // persistent: one per CU
-    const dim3 grid(ngrid), block(GEO::WGW * 64);
-    if constexpr (!GEO::OUTER) {
-      using BD = Body<DevB, GEO, DT>;
-      const int lds = GEO::LDS_BYTES + (d.c.R > 1 ? d.c.R * BD::IPASS_BYTES : 0);
-      int rc = ffc_set_lds(bwd_kernel_small<GEO, DT>, GEO::LDS_BYTES + 2 * BD::IPASS_BYTES);
-      if (rc) return rc;
-      if (d.c.R > 1 && GEO::N != 1024) return ffc_fail("multi-pass plan on a geometry without multi-pass kernels");
-      const int cap = (d.c.persist > 0 && d.c.persist < (1 << 29)) ? 2 * d.c.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
-      hipLaunchKernelGGL((bwd_kernel_small<GEO, DT>), dim3(ngrid > cap ? cap : ngrid), block, lds, st, d);
-    } else {
-      const bool half = (GEO::N1 / 2) * GEO::Mi >= d.c.L;
-      if (half) {
-        {
-          int rc = ffc_set_lds(bwd_kernel<GEO, DT, true>, GEO::LDS_BYTES);
-          if (rc) return rc;
-          hipLaunchKernelGGL((bwd_kernel<GEO, DT, true>), grid, block, GEO::LDS_BYTES, st, d);
-        }
-      } else {
-        int rc = ffc_set_lds(bwd_kernel<GEO, DT, false>, GEO::LDS_BYTES);
-        if (rc) return rc;
-        hipLaunchKernelGGL((bwd_kernel<GEO, DT, false>), grid, block, GEO::LDS_BYTES, st, d);
-      }
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_kernel launch: ") + hipGetErrorString(e));
-  }
-};
 
 #if defined(FFC_BWD_PROF)
 // profiling variant only (build.py --variant bwdprof -DFFC_BWD_PROF): per-phase s_memtime sums, [workgroup][wave][16]
@@ -130,8 +60,9 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H);
 static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
-                         int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
+                         int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream, const void* yraw = nullptr) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
+  if (yraw && (!zin || !dpost)) return ffc_fail("y_raw needs the saved spectra and a dpost output");
   if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -158,13 +89,32 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
   a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate && p->hp.R == 1) ? 1 : 0);    // see Body::STREAM_ROWS
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
-  d.dpost = p->hp.N1 > 1 ? dpost : nullptr;
+  d.dpost = (p->hp.N1 > 1 || yraw) ? dpost : nullptr;      // with y_raw every geometry writes dpost from its dout row load
   d.zin = zin;
-  if (d.dpost && (((uintptr_t)dpost) & 15)) a.fast = 0;
+  d.yraw = yraw;
+  if (yraw && p->hp.R > 1 && p->hp.N1 > 1) {
+    // multi-pass sizes of the fused 32768 kernel: the product runs as a streaming kernel of its own (see mul_rows_kernel)
+    const int64_t HL = H * L;
+    const int fast = (HL % 8 == 0) && !((sb_dout | sb_dpost) & 7) && !(((uintptr_t)dout | (uintptr_t)yraw | (uintptr_t)dpost) & 15);
+    int64_t nb = (HL / (fast ? 8 : 1) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    const dim3 grid((unsigned)nb, (unsigned)B), block(256);
+    if (p->hp.dtype == DT_BF16)
+      hipLaunchKernelGGL(mul_rows_kernel<DT_BF16>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)dout, (const uint16_t*)yraw,
+                         (uint16_t*)dpost, HL, sb_dout, HL, sb_dpost, fast);
+    else
+      hipLaunchKernelGGL(mul_rows_kernel<DT_F16>, grid, block, 0, (hipStream_t)stream, (const uint16_t*)dout, (const uint16_t*)yraw,
+                         (uint16_t*)dpost, HL, sb_dout, HL, sb_dpost, fast);
+    HIPCHK(hipGetLastError());
+    d.dpost = nullptr; d.yraw = nullptr; dpost = nullptr;
+  }
+  if (d.dpost && ((((uintptr_t)dpost) | (uintptr_t)yraw) & 15)) a.fast = 0;
 #if defined(FFC_BWD_PROF)
   a.prof = ffc_bwd_prof_buffer();
 #endif
-  int rc = ffc_dispatch<BwdLaunch>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
+  // fused sizes >= 4096 on saved spectra: the ZM = 1 kernels (ffc_k_bwdz.hip); everything else from this unit
+  int rc = (zin && p->hp.N1 > 1) ? ffc_bwdz_launch(p->hp.N, p->hp.dtype, d, (hipStream_t)stream)
+                                 : ffc_dispatch<BwdLaunchZ<0>::T>(p->hp.N, p->hp.dtype, d, (hipStream_t)stream);
   if (rc || !dpost || d.dpost) return rc;
   return ffc_conv_fwd_strided(p, u, kf, pregate, dout, dpost, B, H, L, 0, sb_u, sb_pre, sb_dout, sb_dpost, stream);
 }
@@ -183,6 +133,16 @@ extern "C" int ffc_conv_bwd_z(const ffc_plan* p, const void* dout, const void* u
   if (!zin) return ffc_fail("null spectrum buffer");
   return conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, sb_dout, sb_u, sb_pre, sb_post, sb_du,
                        sb_dpre, sb_dpost, stream);
+}
+// ... and on the forward output before the postgate multiply that ffc_conv_fwd_z stored (y_raw, contiguous (B,H,L)): dpost =
+// dout * y_raw is written from the registers that hold the dout rows (same fp32 product, rounded once, as the output gate)
+extern "C" int ffc_conv_bwd_zy(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
+                               const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw,
+                               int64_t B, int64_t H, int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                               int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
+  if (!zin || !y_raw || !dpost) return ffc_fail("null spectrum / y_raw / dpost buffer");
+  return conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, sb_dout, sb_u, sb_pre, sb_post, sb_du,
+                       sb_dpre, sb_dpost, stream, y_raw);
 }
 extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
                                   const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,

@@ -45,6 +45,10 @@ struct DkfArgs {
   // optional (ffc_conv_bwd_z): the spectra FFT(u * pregate) saved by the forward pass (ConvArgs::zsave layout).  The kernel
   // then skips its first transform of every pair (rows of u, outer stage, two inner stages, scratch round trip).
   const void* zin;
+  // with zin, optional (ffc_conv_bwd_zy): the forward output before the postgate multiply, contiguous (B,H,L) dtype, as stored by
+  // ffc_conv_fwd_z.  dpost = dout * yraw is then a side product of the dout row load (ConvArgs::aux_in) instead of an inverse
+  // transform of the saved spectrum.
+  const void* yraw;
 };
 
 struct DkArgs {
@@ -767,7 +771,10 @@ struct Modes : Body<B, GEO, DT> {
     BD::cmul_conj(re, im, k);
   }
   // SETUP = false: the plan tables are already in LDS (persistent workgroups of the single-tile sizes copy them once)
-  template <bool HALF = false, bool RP = false, bool SETUP = true>
+  // ZM: 1 = on the spectra the forward pass saved (d.zin), 0 = recomputing, -1 = decided at run time (single-tile kernels).
+  // The fused sizes >= 4096 compile the two forms as separate kernels (bwd_kernel<.., ZM>: ffc_k_bwd.hip / ffc_k_bwdz.hip):
+  // each carries only its own half of the pair loop, and a profile names them apart.
+  template <bool HALF = false, bool RP = false, bool SETUP = true, int ZM = -1>
   static FFC_FN void bwd(const DkfArgs& d, int h, int chunk, int wg_linear, int k0 = 0, int wv_in = 0) {
     const ConvArgs& a = d.c;
     const Pass ps = RP ? make_pass(a.tab, a.t, a.R, k0) : Pass();
@@ -793,6 +800,13 @@ struct Modes : Body<B, GEO, DT> {
     ap.y = d.dpre; ap.postgate = a.u; ap.sby = d.sbdpre; ap.sbp = a.sbu;
     ConvArgs aq = a;            // dpost = conv(u*pregate, k) * dout
     aq.y = d.dpost; aq.postgate = d.dout; aq.sby = d.sbdpost; aq.sbp = d.sbd;
+    // saved forward output (d.yraw): dpost = dout * yraw falls out of the dout row load, no transform for it
+    const bool dpost_tf = d.dpost != nullptr && d.yraw == nullptr;
+    // (not in the multi-pass kernels of the fused 32768 size: their 128-VGPR budget has no room for it, build.py check_agpr;
+    // the launcher runs the product as a streaming kernel of its own there, ffc_k_bwd.hip mul_rows_kernel)
+    if constexpr (!(RP && GEO::OUTER)) {
+      if (d.dpost && d.yraw) { ad.aux_in = d.yraw; ad.aux_out = d.dpost; ad.sbai = (int64_t)a.H * a.L; ad.sbao = d.sbdpost; }
+    }
     // OUTER geometries: one slab per chunk (the units are reduced inside the workgroup); else one per (chunk, unit).
     // Multi-pass sizes: slab rows are (head, pass).
     float* slab = RP ? d.ws + (((int64_t)chunk * a.H + h) * a.R + k0) * (GEO::NT * 2048)
@@ -814,7 +828,7 @@ struct Modes : Body<B, GEO, DT> {
       // before the last scratch store -- needs 32 live registers at points where the allocator, which treats a0..a127 as free
       // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
       // DESIGN.md section 7)
-      const bool have_z = d.zin != nullptr;
+      const bool have_z = ZM < 0 ? d.zin != nullptr : ZM == 1;
       // wave priority by progress between two barriers (Body::outer_jobs has the measurements): row loads 1, phase A 0, the
       // tile loops 3 then 1 (2 for the second-dispatched wave of the SIMD), phase C 3, stores 2
       const bool second = wv >= 4;
@@ -836,7 +850,7 @@ struct Modes : Body<B, GEO, DT> {
                          : RP ? (const void*)BD::z_slot_rp(const_cast<void*>(d.zin), h, a.npair, act ? p : p0, a.R, k0)
                               : (const void*)BD::z_slot(const_cast<void*>(d.zin), h, a.npair, act ? p : p0);
         if (have_z) {
-          if (d.dpost) {
+          if (dpost_tf) {
             // forward output of this pair for dpost: iFFT(Z_u * k_f) into E.  The previous pair's phase C read every E row.
             BD::unit_barrier();
             if (act) {
@@ -892,7 +906,7 @@ struct Modes : Body<B, GEO, DT> {
               A16 re, im;
               BD::template tile_fwd<false>(tau, R, un, re, im);
               z_store(zs, tau, re, im, (a.flags & 4) != 0);
-              if (d.dpost) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
+              if (dpost_tf) {          // forward output of this pair: iFFT(Z_u * k_f) back into E
                 // (k_f is requested only now: held across tile_fwd it overflows the 128-VGPR budget into a0..a127)
                 typename BD::KfRegs kf;
                 BD::load_kf(a, hk, tau, kf);
@@ -905,7 +919,7 @@ struct Modes : Body<B, GEO, DT> {
           BD::unit_barrier();
           FFC_BTICK(4)
           FFC_BPRIO(1)
-          if (d.dpost) {
+          if (dpost_tf) {
             if (act) {
               BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
               B::lds_fence();
@@ -997,6 +1011,7 @@ struct Modes : Body<B, GEO, DT> {
                 z_pack(re, im, zv);
                 B::lds_fence();
               }
+              if (ad.aux_in && k0 == 0) BD::template rows_aux_rp<BD::NCH>(ad, h, q, un);      // dpost = dout * yraw, once per pair
               BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
               B::lds_fence();
               BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);

@@ -138,7 +138,42 @@ def _conv_sparse(plan, u, kf, pregate, postgate, conj, rows):
     return y
 
 
-def _spectrum_buffer(plan, B, H, device, gated=True):
+# Memory budget of the kept spectra: save_spectrum spends memory the reference does not (2x the bytes of u per
+# layer at L = N/2, + 1x gated), and the OutOfMemoryError fallbacks below only see a failure of THESE allocations -- a model that
+# fitted before could run out later, in somebody else's allocation.  So a buffer is only taken when it is at most
+# FFC_SPECTRUM_FRACTION (default 1/8) of the memory that is free at that moment (device free + the caching allocator's unused
+# reserve): layer after layer the rule limits itself, the total can never exceed the free memory at the first layer and the
+# last 7/8 of whatever is left always stay available to the rest of the model.  module.save_spectrum = "always" skips the test.
+_SPEC_FRACTION = float(_os.environ.get("FFC_SPECTRUM_FRACTION", "0.125"))
+_SPEC_SMALL = 8 << 20          # below this a request is not worth a hipMemGetInfo call (the OOM fallback still covers it)
+_free_cache = {}
+
+
+def _free_bytes(device):
+    """free device memory + unused reserve of torch's caching allocator; hipMemGetInfo is queried at most every 10 ms per device
+    (the requests granted in between are subtracted from the cached figure)"""
+    import time
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    now = time.monotonic()
+    c = _free_cache.get(idx)
+    if c is None or now - c[1] > 0.010:
+        free, _ = torch.cuda.mem_get_info(idx)
+        free += torch.cuda.memory_reserved(idx) - torch.cuda.memory_allocated(idx)
+        c = _free_cache[idx] = [free, now]
+    return c
+
+
+def _spectrum_budget_ok(nbytes, device, mode=True):
+    if mode == "always" or nbytes <= _SPEC_SMALL:
+        return True
+    c = _free_bytes(device)
+    if nbytes > _SPEC_FRACTION * c[0]:
+        return False
+    c[0] -= nbytes
+    return True
+
+
+def _spectrum_buffer(plan, B, H, device, gated=True, mode=True):
     """Buffer for the spectra FFT(u * pregate) that the forward pass keeps for the backward pass (ffc_conv_fwd_z / ffc_conv_bwd_z),
     or None: no memory for it (the caller then takes the recomputing path, like the reference).  Every fused plan has the path:
     [H][pair][fft size] complex values, for the single-tile sizes (fft <= 2048) one 4 KB slot per tile and pass."""
@@ -147,7 +182,7 @@ def _spectrum_buffer(plan, B, H, device, gated=True):
     if plan.seqlen <= 1024 and not gated:
         return None
     n = _lib.lib().ffc_spectrum_bytes(plan.handle, B, H)
-    if n <= 0:
+    if n <= 0 or not _spectrum_budget_ok(n, device, mode):
         return None
     try:
         return torch.empty(n, dtype=torch.uint8, device=device)
@@ -239,7 +274,7 @@ class _TorchOps:
     def conv_save(self, dt, M, x, kf):
         """inner forward that also keeps the inner spectra (None when the inner plan has no such path)"""
         plan = self._plan(M)
-        z = _spectrum_buffer(plan, x.shape[0], x.shape[1], self.device)
+        z = _spectrum_buffer(plan, x.shape[0], x.shape[1], self.device, True, self.mod.save_spectrum)
         return (_conv(plan, x, kf, None, None, False), None) if z is None else (_conv_save(plan, x, kf, None, None, z), z)
 
     def bwd(self, dt, M, xd, xu, kf, z=None):
@@ -382,6 +417,8 @@ class _FlashFFTConvFn(torch.autograd.Function):
         kept = None
         if ctx.big:
             keep = mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+            if keep:      # kept: inner-size rows x (4 B per point and pair), their spectra z (4 B), gated also the inner output y (4 B)
+                keep = _spectrum_budget_ok(((u.shape[0] + 1) // 2) * u.shape[1] * mod.seqlen * (12 if ctx.gated else 8), u.device, mod.save_spectrum)
             # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
             ctx.fac = fac = _big.choose(mod.seqlen, max(u.shape[-1], k.shape[-1]), _TorchOps)
             try:
@@ -410,7 +447,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if rows:
                 out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
             elif mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
-                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated)
+                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated, mod.save_spectrum)
                 if z is not None and ctx.gated:
                     try:
                         yraw = torch.empty_like(u)
@@ -461,10 +498,13 @@ class _FlashFFTConvFn(torch.autograd.Function):
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
-        dpost = torch.empty_like(u) if ctx.gated and z is None else None
-        if z is not None:
-            if ctx.gated:
-                dpost = dout * yraw      # same product and rounding as the kernel's output gate (fp32 product of the two, rounded once)
+        dpost = torch.empty_like(u) if ctx.gated else None
+        if z is not None and ctx.gated:
+            # dpostgate = dout * y_raw out of the kernel's dout row load (round 3: a torch elementwise kernel, 3 x |u| bytes more)
+            _lib.check(lib.ffc_conv_bwd_zy(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
+                                           _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws), _lib.ptr(z),
+                                           _lib.ptr(yraw), B, H, L, 0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_bwd_zy")
+        elif z is not None:
             _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
                                           _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), None, _lib.ptr(ws), _lib.ptr(z),
                                           B, H, L, 0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
@@ -527,7 +567,10 @@ class FlashFFTConv(torch.nn.Module):
         self.cache_kf = False
         self._kf_cache = None
         # training forward keeps FFT(u) for the backward pass (see _FlashFFTConvFn._forward); FFC_SAVE_SPECTRUM=0 turns it off
-        self.save_spectrum = _os.environ.get("FFC_SAVE_SPECTRUM", "1") != "0"
+        # True: when the buffer fits the memory budget (_spectrum_budget_ok: at most 1/8 of the free memory at that moment);
+        # "always" (FFC_SAVE_SPECTRUM=always): whenever the allocation succeeds; False: never (the reference's footprint)
+        _sv = _os.environ.get("FFC_SAVE_SPECTRUM", "1")
+        self.save_spectrum = False if _sv == "0" else ("always" if _sv == "always" else True)
 
     def _cached_kf(self, k):
         c = self._kf_cache

@@ -43,7 +43,7 @@ class _GatedSlicesFn(torch.autograd.Function):
             # training: keep the spectra FFT(x1 * v) and the output before the x2 multiply (FlashFFTConv.save_spectrum)
             z = yraw = None
             if mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[:2]):
-                z = _spectrum_buffer(plan, B, D, uc.device)
+                z = _spectrum_buffer(plan, B, D, uc.device, True, mod.save_spectrum)
                 if z is not None:
                     try:
                         yraw = torch.empty_like(y)
@@ -80,11 +80,11 @@ class _GatedSlicesFn(torch.autograd.Function):
             sb = D3 * L
             # u = v (slice 2), pregate = x1 (slice 0), postgate = x2 (slice 1); gradients land in the same slices of duc
             if z is not None:
-                torch.mul(dy, yraw, out=duc.view(B, 3, D, L)[:, 1])         # d x2 = dy * (output before the x2 multiply)
-                _lib.check(lib.ffc_conv_bwd_z(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
-                                              _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
-                                              _slice_ptr(duc, 0, D, L), None, _lib.ptr(ws), _lib.ptr(z), B, D, L,
-                                              0, sb, sb, sb, sb, sb, 0, _lib.stream_ptr()), "ffc_conv_bwd_z")
+                # d x2 = dy * (output before the x2 multiply): written into its slice of duc by the kernel's dy row load
+                _lib.check(lib.ffc_conv_bwd_zy(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
+                                               _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
+                                               _slice_ptr(duc, 0, D, L), _slice_ptr(duc, 1, D, L), _lib.ptr(ws), _lib.ptr(z), _lib.ptr(yraw),
+                                               B, D, L, 0, sb, sb, sb, sb, sb, sb, _lib.stream_ptr()), "ffc_conv_bwd_zy")
             else:
               _lib.check(lib.ffc_conv_bwd_gated_strided(plan.handle, _lib.ptr(dy), _slice_ptr(uc, 2, D, L), _lib.ptr(kf),
                                                       _slice_ptr(uc, 0, D, L), _slice_ptr(uc, 1, D, L), _slice_ptr(duc, 2, D, L),
@@ -221,17 +221,20 @@ def project_in(weight, u, bias=None):
     operand writes out of bounds at D = 768, L >= 8192 -- hipBLASLt and rocBLAS alike, the reference's own matmul form included;
     benchmarks/scratch/bmm_fault2.py.  The 2-D GEMM is the path every nn.Linear takes.)"""
     if u.shape[0] > _LOOP_MAX_BATCH:      # many short sequences: one GEMM + the layout copy, which is small there
-        out = torch.nn.functional.linear(u, weight).transpose(-1, -2).contiguous()
+        # (fp32 master weights under mixed precision: cast like _ProjectIn does; autograd returns the gradient in the weight's dtype)
+        out = torch.nn.functional.linear(u, weight if weight.dtype == u.dtype else weight.to(u.dtype)).transpose(-1, -2).contiguous()
     else:
         out = _ProjectIn.apply(weight, u)
-    return out if bias is None else out + bias.view(1, -1, 1)
+    return out if bias is None else out + bias.to(out.dtype).view(1, -1, 1)
 
 
 def project_out(weight, bias, y):
     """out-projection of a channels-first (B, D, L) result back to (B, L, C): nn.Linear on y.transpose(-1, -2) first copies
     the transposed view (55 of 88 us at the shape above); a 2-D GEMM per batch row reads y[b].t() as its transposed operand."""
     if y.shape[0] > _LOOP_MAX_BATCH:
-        return torch.nn.functional.linear(y.transpose(-1, -2), weight, bias)
+        w = weight if weight.dtype == y.dtype else weight.to(y.dtype)
+        bb = bias if bias is None or bias.dtype == y.dtype else bias.to(y.dtype)
+        return torch.nn.functional.linear(y.transpose(-1, -2), w, bb)
     return _ProjectOut.apply(weight, bias, y)
 
 

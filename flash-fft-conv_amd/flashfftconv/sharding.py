@@ -15,6 +15,11 @@ RCCL/xGMI (backend "nccl"); every (b, h) row is independent given k[h], so there
                                  smaller ones, the HBM-level sizes (>= 262144) exchange the rows of their inner size
                                  (_BigOps); only the folded and the frequency-sparse forms fall back to recompute.
 
+Collectives are issued with async_op=True and waited for where their result is first needed (_Pending): RCCL runs them on the
+process group's stream, so the kernels launched in between overlap them; the B-shard cuts the heads into groups to have such
+kernels (_BShardFn).  Which collective a backend supports is probed once per group (_caps), never decided by catching an error
+around a live collective.
+
 The compute goes through an `ops` object (GPU: _HipOps over the C-ABI; CPU tests: a torch.fft stand-in) so the collective
 logic is exercised by world_size-2 gloo tests without a GPU.  The reference has no distributed code; this is new."""
 import torch
@@ -35,49 +40,147 @@ def shard_heads(x, dim, rank=None, world=None):
     return x.narrow(dim, s, e - s).contiguous()
 
 
-def _all_gather_uneven(x_local, H, dim, group=None):
-    """All-gather head shards back to the full tensor (uneven shards supported via padding)."""
+def _sizes(H, world):
+    return [head_range(H, r, world)[1] - head_range(H, r, world)[0] for r in range(world)]
+
+
+# Which collectives a process group has is decided ONCE per (group, device type), by the same tiny probe on every rank, and
+# cached (a try / except around a live collective lets one rank that fails locally -- out of memory, an async RCCL
+# error -- fall into a different collective than its peers: a hang instead of an error).  A backend either has the tensor
+# collectives or raises before it communicates, so the ranks agree.
+_CAPS = {}
+
+
+def _caps(group, like):
+    key = (id(group) if group is not None else None, like.device.type)
+    c = _CAPS.get(key)
+    if c is None:
+        if dist.get_backend(group) == "nccl":          # RCCL: both tensor collectives
+            c = (True, True)
+        else:
+            world = dist.get_world_size(group)
+            one, many = like.new_zeros(1, dtype=torch.float32), like.new_zeros(world, dtype=torch.float32)
+            ag = rs = True
+            try:
+                dist.all_gather_into_tensor(many, one, group=group)
+            except (RuntimeError, NotImplementedError):
+                ag = False
+            try:
+                dist.reduce_scatter_tensor(one, many, group=group)
+            except (RuntimeError, NotImplementedError):
+                rs = False
+            c = (ag, rs)
+        _CAPS[key] = c
+    return c
+
+
+class _Pending:
+    """a collective in flight: issued with async_op=True (RCCL runs it on the process group's own stream, behind an event
+    recorded on the compute stream at issue time, so kernels launched afterwards overlap it); wait() makes the compute stream
+    wait for it -- no host synchronisation with RCCL -- and returns the result"""
+
+    def __init__(self, work, finish):
+        self.work, self.finish = work, finish
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.finish()
+
+
+def _all_gather_heads_async(x_local, H, group=None):
+    """all-gather of head shards along dim 0 (uneven shards: padded to the largest one) -> _Pending of the (H, ...) tensor"""
     world = dist.get_world_size(group)
-    sizes = [head_range(H, r, world)[1] - head_range(H, r, world)[0] for r in range(world)]
+    sizes = _sizes(H, world)
     m = max(sizes)
-    if all(s == m for s in sizes) and dim == 0 and x_local.is_contiguous():
-        out = x_local.new_empty((H,) + tuple(x_local.shape[1:]))
-        try:        # one tensor collective (RCCL; gloo has it for CPU tensors)
-            dist.all_gather_into_tensor(out, x_local, group=group)
-        except (RuntimeError, NotImplementedError):
-            dist.all_gather(list(out.chunk(world, 0)), x_local, group=group)
+    x_local = x_local.contiguous()
+    tail = tuple(x_local.shape[1:])
+    ag_tensor, _ = _caps(group, x_local)
+    if all(sz == m for sz in sizes):
+        out = x_local.new_empty((H,) + tail)
+        if ag_tensor:
+            w = dist.all_gather_into_tensor(out, x_local, group=group, async_op=True)
+        else:
+            w = dist.all_gather(list(out.chunk(world, 0)), x_local, group=group, async_op=True)
+        return _Pending(w, lambda: out)
+    buf = x_local.new_zeros((m,) + tail)
+    buf[: x_local.shape[0]].copy_(x_local)
+    padded = x_local.new_empty((world * m,) + tail)
+    if ag_tensor:
+        w = dist.all_gather_into_tensor(padded, buf, group=group, async_op=True)
+    else:
+        w = dist.all_gather(list(padded.chunk(world, 0)), buf, group=group, async_op=True)
+
+    def strip():
+        out = x_local.new_empty((H,) + tail)
+        at = 0
+        for r, sz in enumerate(sizes):
+            out[at:at + sz].copy_(padded[r * m:r * m + sz])
+            at += sz
         return out
+    return _Pending(w, strip)
+
+
+def _reduce_scatter_heads_async(x_full, group=None):
+    """sum over the ranks of x_full (H, ...), this rank's head range of the result -> _Pending.  Uneven shards go through a padded
+    reduce_scatter_tensor (round 3 all-reduced a clone of the whole tensor: 201 MB per rank at config 2 for H = 111-style shapes);
+    a backend without the tensor collective (gloo) all-reduces."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    H = x_full.shape[0]
+    sizes = _sizes(H, world)
+    m = max(sizes)
+    tail = tuple(x_full.shape[1:])
+    x_full = x_full.contiguous()
+    _, rs_tensor = _caps(group, x_full)
+    s, e = head_range(H, rank, world)
+    if not rs_tensor:
+        x = x_full.clone()
+        w = dist.all_reduce(x, group=group, async_op=True)
+        return _Pending(w, lambda: x[s:e].contiguous())
+    if all(sz == m for sz in sizes):
+        out = x_full.new_empty((m,) + tail)
+        w = dist.reduce_scatter_tensor(out, x_full, group=group, async_op=True)
+        return _Pending(w, lambda: out)
+    padded = x_full.new_zeros((world * m,) + tail)
+    at = 0
+    for r, sz in enumerate(sizes):
+        padded[r * m:r * m + sz].copy_(x_full[at:at + sz])
+        at += sz
+    out = x_full.new_empty((m,) + tail)
+    w = dist.reduce_scatter_tensor(out, padded, group=group, async_op=True)
+    return _Pending(w, lambda: out[: e - s])
+
+
+def _all_gather_uneven(x_local, H, dim, group=None):
+    """All-gather head shards back to the full tensor along `dim` (uneven shards supported via padding)."""
+    if dim == 0:
+        return _all_gather_heads_async(x_local, H, group).wait()
+    world = dist.get_world_size(group)
+    sizes = _sizes(H, world)
+    m = max(sizes)
     pad_shape = list(x_local.shape); pad_shape[dim] = m
     buf = x_local.new_zeros(pad_shape)
     buf.narrow(dim, 0, x_local.shape[dim]).copy_(x_local)
     outs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(outs, buf, group=group)
-    return torch.cat([o.narrow(dim, 0, s) for o, s in zip(outs, sizes)], dim=dim)
+    return torch.cat([o.narrow(dim, 0, sz) for o, sz in zip(outs, sizes)], dim=dim)
 
 
 def _reduce_scatter_heads(x_full, dim, group=None):
     """sum over ranks of x_full, this rank's head range of the result."""
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    H = x_full.shape[dim]
-    s, e = head_range(H, rank, world)
-    if H % world == 0 and dim == 0 and x_full.is_contiguous():
-        out = x_full.new_empty((H // world,) + tuple(x_full.shape[1:]))
-        try:        # one tensor collective (RCCL; gloo has it for CPU tensors)
-            dist.reduce_scatter_tensor(out, x_full, group=group)
-            return out
-        except (RuntimeError, NotImplementedError):
-            pass
-    x = x_full.clone()
-    dist.all_reduce(x, group=group)          # gloo (CPU tests / same-GPU tests) and uneven shards
-    return x.narrow(dim, s, e - s).contiguous()
+    if dim == 0:
+        return _reduce_scatter_heads_async(x_full, group).wait()
+    return _reduce_scatter_heads_async(x_full.movedim(dim, 0).contiguous(), group).wait().movedim(0, dim).contiguous()
 
 
-def _all_gather_rows(x_local, H, rows, group=None):
+def _all_gather_rows_async(x_local, H, rows, group=None):
     """all-gather of head shards whose dim 0 is (head, row) with `rows` rows per head"""
     if rows == 1:
-        return _all_gather_uneven(x_local, H, 0, group)
-    full = _all_gather_uneven(x_local.reshape((-1, rows) + tuple(x_local.shape[1:])), H, 0, group)
-    return full.reshape((H * rows,) + tuple(x_local.shape[1:]))
+        return _all_gather_heads_async(x_local, H, group)
+    tail = tuple(x_local.shape[1:])
+    p = _all_gather_heads_async(x_local.reshape((-1, rows) + tail), H, group)
+    return _Pending(None, lambda: p.wait().reshape((H * rows,) + tail))
 
 
 class _GatherHeads(torch.autograd.Function):
@@ -119,7 +222,9 @@ class HeadShardedFFTConv(torch.nn.Module):
 
 # ------------------------------------------------------------------------------------------------ B-shard
 class _HipOps:
-    """GPU backend of the B-shard: the C-ABI entry points of one fused plan."""
+    """GPU backend of the B-shard: the C-ABI entry points of one fused plan.  Every call works on a HEAD RANGE [g0, g1) of
+    (B, H, L) tensors in place (batch-strided entry points): the head groups of the pipelined B-shard (_BShardFn) need no copies."""
+    SLICES = True
 
     def __init__(self, mod, device):
         from . import conv as C, _lib
@@ -131,37 +236,78 @@ class _HipOps:
             return torch.empty(0, self.plan.kf_elems, 2, dtype=self.plan.dtype, device=k.device)
         return self.C._kernel_fft(self.plan, k)
 
+    def _sp(self, t, g0):
+        """pointer to head g0 of a contiguous (B, H, L) tensor (None stays None)"""
+        import ctypes
+        return None if t is None else ctypes.c_void_p(t.data_ptr() + g0 * t.shape[-1] * t.element_size())
+
+    def conv_slice(self, u, kf, pre, post, out, g0, g1, keep):
+        """out[:, g0:g1] = conv of heads [g0, g1) with their k_f rows `kf`; keep: also store the spectra (+ the output before the
+        postgate) for backward_slice -> (z, yraw) or None"""
+        L, lib = self.L, self.L.lib()
+        B, H, Lu = u.shape
+        hg, sb = g1 - g0, H * Lu
+        if hg == 0:
+            return None
+        z = yraw = None
+        if keep and self.mod.save_spectrum:
+            z = self.C._spectrum_buffer(self.plan, B, hg, u.device, pre is not None, self.mod.save_spectrum)
+            if z is not None and pre is not None:
+                try:
+                    yraw = torch.empty(B, hg, Lu, dtype=u.dtype, device=u.device)
+                except torch.cuda.OutOfMemoryError:      # same fallback as the single-rank module (ADVICE r03)
+                    z = None
+        if z is None:
+            L.check(lib.ffc_conv_fwd_strided(self.plan.handle, self._sp(u, g0), L.ptr(kf), self._sp(pre, g0), self._sp(post, g0),
+                                             self._sp(out, g0), B, hg, Lu, 0, sb, sb, sb, sb, L.stream_ptr()), "ffc_conv_fwd_strided")
+            return None
+        L.check(lib.ffc_conv_fwd_z(self.plan.handle, self._sp(u, g0), L.ptr(kf), self._sp(pre, g0), self._sp(post, g0), self._sp(out, g0),
+                                   L.ptr(z), L.ptr(yraw), B, hg, Lu, sb, sb, sb, sb, L.stream_ptr()), "ffc_conv_fwd_z")
+        return (z, yraw)
+
+    def backward_slice(self, dout, u, kf, pre, post, du, dpre, dpost, g0, g1, kept=None):
+        """gradients of heads [g0, g1) written into their slices of du / dpre / dpost -> dk_f (hg, kf_elems, 2) fp32, summed over
+        the local batch"""
+        lib, L = self.L.lib(), self.L
+        B, H, Lu = u.shape
+        hg, sb = g1 - g0, H * Lu
+        if hg == 0:
+            return torch.empty(0, self.plan.kf_elems, 2, dtype=torch.float32, device=u.device)
+        ws = torch.empty(lib.ffc_dkf_workspace_bytes(self.plan.handle, B, hg), dtype=torch.uint8, device=u.device)
+        if kept is not None and pre is not None:
+            z, yraw = kept
+            L.check(lib.ffc_conv_bwd_zy(self.plan.handle, self._sp(dout, g0), self._sp(u, g0), L.ptr(kf), self._sp(pre, g0), self._sp(post, g0),
+                                        self._sp(du, g0), self._sp(dpre, g0), self._sp(dpost, g0), L.ptr(ws), L.ptr(z), L.ptr(yraw),
+                                        B, hg, Lu, sb, sb, sb, sb, sb, sb, sb, L.stream_ptr()), "ffc_conv_bwd_zy")
+        elif kept is not None:
+            L.check(lib.ffc_conv_bwd_z(self.plan.handle, self._sp(dout, g0), self._sp(u, g0), L.ptr(kf), None, None, self._sp(du, g0), None,
+                                       None, L.ptr(ws), L.ptr(kept[0]), B, hg, Lu, sb, sb, sb, sb, sb, sb, sb, L.stream_ptr()), "ffc_conv_bwd_z")
+        else:
+            L.check(lib.ffc_conv_bwd_gated_strided(self.plan.handle, self._sp(dout, g0), self._sp(u, g0), L.ptr(kf), self._sp(pre, g0),
+                                                   self._sp(post, g0), self._sp(du, g0), self._sp(dpre, g0), self._sp(dpost, g0), L.ptr(ws),
+                                                   B, hg, Lu, sb, sb, sb, sb, sb, sb, sb, L.stream_ptr()), "ffc_conv_bwd_gated_strided")
+        nslab = lib.ffc_dkf_slab_count(self.plan.handle, B, hg)
+        nfl = hg * self.plan.kf_elems * 2
+        slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, hg, self.plan.kf_elems, 2)
+        return slabs[0] if nslab == 1 else slabs.sum(0)
+
+    # whole-tensor forms (one head group)
     def conv(self, u, kf, pre, post):
-        return self.C._conv(self.plan, u, kf, pre, post, False)
+        out = torch.empty_like(u)
+        self.conv_slice(u, kf, pre, post, out, 0, u.shape[1], False)
+        return out
 
     def conv_keep(self, u, kf, pre, post):
-        """training forward: (out, kept) with kept = (spectra, output before the postgate) or None (FlashFFTConv.save_spectrum)"""
-        z = self.C._spectrum_buffer(self.plan, u.shape[0], u.shape[1], u.device, pre is not None) if self.mod.save_spectrum else None
-        if z is None:
-            return self.conv(u, kf, pre, post), None
-        yraw = torch.empty_like(u) if pre is not None else None
-        return self.C._conv_save(self.plan, u, kf, pre, post, z, yraw), (z, yraw)
+        out = torch.empty_like(u)
+        return out, self.conv_slice(u, kf, pre, post, out, 0, u.shape[1], True)
 
     def backward(self, dout, u, kf, pre, post, kept=None):
         """-> du, dpre, dpost, dk_f (H, kf_elems, 2) fp32 summed over the local batch"""
-        lib, L = self.L.lib(), self.L
-        B, H, Lu = u.shape
-        ws = torch.empty(lib.ffc_dkf_workspace_bytes(self.plan.handle, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if pre is not None else None
-        if kept is not None:
-            z, yraw = kept
-            dpost = dout * yraw if pre is not None else None
-            L.check(lib.ffc_conv_bwd_z(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du), L.ptr(dpre),
-                                       None, L.ptr(ws), L.ptr(z), B, H, Lu, 0, 0, 0, 0, 0, 0, 0, L.stream_ptr()), "ffc_conv_bwd_z")
-        else:
-            dpost = torch.empty_like(u) if pre is not None else None
-            L.check(lib.ffc_conv_bwd_gated(self.plan.handle, L.ptr(dout), L.ptr(u), L.ptr(kf), L.ptr(pre), L.ptr(post), L.ptr(du),
-                                           L.ptr(dpre), L.ptr(dpost), L.ptr(ws), B, H, Lu, L.stream_ptr()), "ffc_conv_bwd_gated")
-        nslab = lib.ffc_dkf_slab_count(self.plan.handle, B, H)
-        nfl = H * self.plan.kf_elems * 2
-        slabs = ws[: nslab * nfl * 4].view(torch.float32).view(nslab, H, self.plan.kf_elems, 2)
-        return du, dpre, dpost, (slabs[0] if nslab == 1 else slabs.sum(0))
+        dpost = torch.empty_like(u) if pre is not None else None
+        dkf = self.backward_slice(dout, u, kf, pre, post, du, dpre, dpost, 0, u.shape[1], kept)
+        return du, dpre, dpost, dkf
 
     def dk_from_dkf(self, dkf, Lk):                # (h, kf_elems, 2) fp32 -> (h, Lk) fp32
         L = self.L
@@ -196,7 +342,14 @@ class _BigOps:
         return self.C._big_forward(self.mod, u, None, pre, post, False, kf)[0]
 
     def conv_keep(self, u, kf, pre, post):
-        out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, bool(self.mod.save_spectrum), kf)
+        keep = bool(self.mod.save_spectrum) and self.C._spectrum_budget_ok(
+            ((u.shape[0] + 1) // 2) * u.shape[1] * self.mod.seqlen * (12 if pre is not None else 8), u.device, self.mod.save_spectrum)
+        try:
+            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, keep, kf)
+        except torch.cuda.OutOfMemoryError:      # same retry as the single-rank module
+            if not keep:
+                raise
+            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, False, kf)
         return out, kept
 
     def backward(self, dout, u, kf, pre, post, kept=None):
@@ -209,55 +362,132 @@ class _BigOps:
         return self.C._big_dk_from_dkf(self.mod, dkf, Lk)
 
 
+def head_groups(H, world, ngroups):
+    """the pipelined B-shard's head groups: `ngroups` contiguous ranges; inside a group rank r owns head_range(size, r, world)"""
+    ngroups = max(1, min(int(ngroups), max(H // max(world, 1), 1)))
+    return [head_range(H, g, ngroups) for g in range(ngroups)]
+
+
+def _default_groups(H, world, ops):
+    import os
+    if not getattr(ops, "SLICES", False) and not getattr(ops, "GENERIC_SLICES", False):
+        return 1                 # HBM-level sizes: no in-place head ranges
+    e = os.environ.get("FFC_SHARD_GROUPS")
+    if e:
+        return max(1, int(e))
+    return 2 if H >= 16 * world else 1
+
+
 class _BShardFn(torch.autograd.Function):
+    """Head-group pipeline (SURVEY 8(e) notes).  The heads are cut into G groups; inside a group every rank owns
+    1/W of the heads.  Forward: each rank transforms its heads of EVERY group first and starts the G k_f all-gathers
+    (async_op: RCCL runs them on its own stream); group g's convolution waits for gather g only, so gathers g+1 .. run under it.
+    Backward: group g's fused backward kernel, then its fp32 dk_f reduce-scatter in flight while group g+1 computes; the
+    per-group dk inverses and dk all-gathers are chained the same way.  G = 1 is the unpipelined form (HBM-level sizes)."""
+
     @staticmethod
-    def forward(ctx, u, k, pre, post, ops, group, training, keep=True):
+    def forward(ctx, u, k, pre, post, ops, group, training, keep=True, ngroups=1):
         H, Lk = k.shape
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        s, e = head_range(H, rank, world)
         rows = getattr(ops, "rows", 1)          # exchanged rows per head (1 for the fused plans)
-        kf_local = ops.kernel_fft(k.detach()[s:e].to(torch.float32).contiguous())      # (an empty shard when H < world)
-        kf = _all_gather_rows(kf_local, H, rows, group)                # the path's one forward collective
+        groups = head_groups(H, world, ngroups)
+        k32 = k.detach().to(torch.float32)
+        pend = []
+        for (g0, g1) in groups:                 # every group's local transform + its all-gather, issued up front
+            s, e = head_range(g1 - g0, rank, world)
+            kf_local = ops.kernel_fft(k32[g0 + s:g0 + e].contiguous())      # (an empty shard when the group has < world heads)
+            pend.append(_all_gather_rows_async(kf_local, g1 - g0, rows, group))
         u = u.contiguous()
         pre = None if pre is None else pre.contiguous()
         post = None if post is None else post.contiguous()
-        kept = None
-        if training and keep and hasattr(ops, "conv_keep"):
-            out, kept = ops.conv_keep(u, kf, pre, post)
+        do_keep = training and keep
+        kfs, kepts = [], []
+        if len(groups) == 1:
+            kf = pend[0].wait()
+            kfs.append(kf)
+            if do_keep and hasattr(ops, "conv_keep"):
+                out, kept = ops.conv_keep(u, kf, pre, post)
+            else:
+                out, kept = ops.conv(u, kf, pre, post), None
+            kepts.append(kept)
         else:
-            out = ops.conv(u, kf, pre, post)
-        ctx.kept_layout = None if kept is None else tuple(t is not None for t in kept)
-        ctx.ops, ctx.group, ctx.Lk, ctx.k_dtype, ctx.gated, ctx.H, ctx.rows = ops, group, Lk, k.dtype, pre is not None, H, rows
+            out = torch.empty_like(u)
+            for (g0, g1), p in zip(groups, pend):
+                kf = p.wait()
+                kfs.append(kf)
+                kepts.append(_conv_group(ops, u, kf, pre, post, out, g0, g1, do_keep))
+        ctx.ops, ctx.group, ctx.Lk, ctx.k_dtype, ctx.gated, ctx.H, ctx.rows, ctx.groups = ops, group, Lk, k.dtype, pre is not None, H, rows, groups
         if training:
-            extra = () if kept is None else tuple(t for t in kept if t is not None)
-            ctx.save_for_backward(*(((u, kf, pre, post) if pre is not None else (u, kf)) + extra))
+            flat, layout = [], []
+            for kept in kepts:
+                layout.append(None if kept is None else tuple(t is not None for t in kept))
+                if kept is not None:
+                    flat += [t for t in kept if t is not None]
+            ctx.kept_layout = layout
+            ctx.save_for_backward(*(((u, pre, post) if pre is not None else (u,)) + tuple(kfs) + tuple(flat)))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         if not ctx.saved_tensors:
             raise RuntimeError("BatchShardedFFTConv: backward needs module.training=True at forward time")
-        nb = 4 if ctx.gated else 2
+        sv = list(ctx.saved_tensors)
         if ctx.gated:
-            u, kf, pre, post = ctx.saved_tensors[:4]
+            u, pre, post = sv[:3]; sv = sv[3:]
         else:
-            (u, kf), pre, post = ctx.saved_tensors[:2], None, None
-        kept = None
-        if ctx.kept_layout is not None:
-            it = iter(ctx.saved_tensors[nb:])
-            kept = tuple(next(it) if present else None for present in ctx.kept_layout)
+            u, pre, post = sv[0], None, None; sv = sv[1:]
+        groups, ops, rows = ctx.groups, ctx.ops, ctx.rows
+        kfs, sv = sv[:len(groups)], sv[len(groups):]
+        it = iter(sv)
+        kepts = [None if lay is None else tuple(next(it) if present else None for present in lay) for lay in ctx.kept_layout]
         import contextlib
         with (torch.cuda.device(u.device) if u.is_cuda else contextlib.nullcontext()):
-            if kept is not None:
-                du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post, kept)
+            dout = dout.contiguous()
+            rs = []
+            if len(groups) == 1:
+                args = (dout, u, kfs[0], pre, post) + ((kepts[0],) if kepts[0] is not None else ())
+                du, dpre, dpost, dkf = ops.backward(*args)
+                rs.append(_reduce_scatter_heads_async(dkf.contiguous().view((ctx.H, rows) + tuple(dkf.shape[1:])), ctx.group))
             else:
-                du, dpre, dpost, dkf = ctx.ops.backward(dout.contiguous(), u, kf, pre, post)
-            H, rows = ctx.H, ctx.rows
-            # fp32 sums over every rank's batch rows; (H, rows, ...) view so that the partition is the head partition
-            dkf_local = _reduce_scatter_heads(dkf.contiguous().view((H, rows) + tuple(dkf.shape[1:])), 0, ctx.group)
-            dk_local = ctx.ops.dk_from_dkf(dkf_local.reshape((-1,) + tuple(dkf.shape[1:])), ctx.Lk)
-            dk = _all_gather_uneven(dk_local, H, 0, ctx.group)        # replicated parameter -> full gradient everywhere
-        return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None, None
+                du = torch.empty_like(u)
+                dpre = torch.empty_like(u) if ctx.gated else None
+                dpost = torch.empty_like(u) if ctx.gated else None
+                for (g0, g1), kf, kept in zip(groups, kfs, kepts):
+                    dkf = _backward_group(ops, dout, u, kf, pre, post, du, dpre, dpost, g0, g1, kept)
+                    # fp32 sums over every rank's batch rows of this group, in flight while the next group computes
+                    rs.append(_reduce_scatter_heads_async(dkf.contiguous().view((g1 - g0, rows) + tuple(dkf.shape[1:])), ctx.group))
+            ag = []
+            for (g0, g1), p in zip(groups, rs):
+                dkf_local = p.wait()
+                dk_local = ops.dk_from_dkf(dkf_local.reshape((-1,) + tuple(dkf_local.shape[2:])), ctx.Lk)
+                ag.append(_all_gather_heads_async(dk_local, g1 - g0, ctx.group))      # replicated parameter -> full gradient everywhere
+            parts = [p.wait() for p in ag]
+            dk = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        return du, dk.to(ctx.k_dtype), dpre, dpost, None, None, None, None, None
+
+
+def _conv_group(ops, u, kf, pre, post, out, g0, g1, keep):
+    if getattr(ops, "SLICES", False):
+        return ops.conv_slice(u, kf, pre, post, out, g0, g1, keep)
+    sl = lambda t: None if t is None else t[:, g0:g1].contiguous()      # generic ops (CPU stand-in): on copies of the head range
+    if keep and hasattr(ops, "conv_keep"):
+        y, kept = ops.conv_keep(sl(u), kf, sl(pre), sl(post))
+    else:
+        y, kept = ops.conv(sl(u), kf, sl(pre), sl(post)), None
+    out[:, g0:g1] = y
+    return kept
+
+
+def _backward_group(ops, dout, u, kf, pre, post, du, dpre, dpost, g0, g1, kept):
+    if getattr(ops, "SLICES", False):
+        return ops.backward_slice(dout, u, kf, pre, post, du, dpre, dpost, g0, g1, kept)
+    sl = lambda t: None if t is None else t[:, g0:g1].contiguous()
+    args = (sl(dout), sl(u), kf, sl(pre), sl(post)) + ((kept,) if kept is not None else ())
+    a, b, c, dkf = ops.backward(*args)
+    du[:, g0:g1] = a
+    if pre is not None:
+        dpre[:, g0:g1] = b; dpost[:, g0:g1] = c
+    return dkf
 
 
 class _AllReduceGrad(torch.autograd.Function):
@@ -280,10 +510,11 @@ class BatchShardedFFTConv(torch.nn.Module):
     rows and k the full replicated (H, Lk) filter; returns the local rows of y.  k.grad is the gradient summed over ALL
     ranks' batch rows (identical on every rank).  See the module docstring for the two modes."""
 
-    def __init__(self, conv, mode="allgather_kf", group=None, ops=None):
+    def __init__(self, conv, mode="allgather_kf", group=None, ops=None, groups=None):
         super().__init__()
         assert mode in ("allgather_kf", "recompute")
         self.conv, self.mode, self.group, self._ops = conv, mode, group, ops
+        self.groups = groups        # head groups of the pipelined exchange (None: 2 when H >= 16 x world, FFC_SHARD_GROUPS overrides)
 
     def forward(self, u, k, pregate=None, postgate=None):
         if pregate is not None or postgate is not None:
@@ -298,9 +529,13 @@ class BatchShardedFFTConv(torch.nn.Module):
         ops = self._ops if self._ops is not None else (_BigOps if self.conv._big else _HipOps)(self.conv, u.device)
         training = self.conv.training if hasattr(self.conv, "training") else True
         keep = training and torch.is_grad_enabled()      # spectra are only worth storing when a graph is being recorded
+        world = dist.get_world_size(self.group)
+        ng = self.groups if self.groups is not None else _default_groups(k.shape[0], world, ops)
+        if not (getattr(ops, "SLICES", False) or getattr(ops, "GENERIC_SLICES", False)):
+            ng = 1
         if self._ops is None:
             from .conv import _check_inputs
             _check_inputs(self.conv, u, k, (pregate, postgate))
             with torch.cuda.device(u.device):
-                return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep)
-        return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep)
+                return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep, ng)
+        return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep, ng)

@@ -107,6 +107,13 @@ int ffc_conv_bwd_z(const ffc_plan* plan, const void* dout, const void* u, const 
                    const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
                    int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post, int64_t sb_du, int64_t sb_dpre,
                    int64_t sb_dpost, void* stream);
+/* ffc_conv_bwd_z with the y_raw that ffc_conv_fwd_z stored: dpost = dout * y_raw (fp32 product, rounded once: the same
+ * arithmetic as the forward's output gate) is written while the kernel loads the rows of dout -- all five gradients of the gated
+ * backward from one launch, as reference flashfftconv/conv.py:3979 returns them from native code; no third transform. */
+int ffc_conv_bwd_zy(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate,
+                    const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw,
+                    int64_t B, int64_t H, int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
+                    int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

@@ -26,11 +26,12 @@ def test_projections_match_the_reference_forms(B):
     assert torch.allclose(project_out(Wo, None, y), y.transpose(-1, -2) @ Wo.t(), atol=1e-12)
 
 
-def test_projections_take_fp32_master_weights():
+@pytest.mark.parametrize("B", [2, 20])      # 20 > the per-row loop limit (that branch lacked the cast)
+def test_projections_take_fp32_master_weights(B):
     """bf16 activations with fp32 weights (mixed-precision training): cast inside, gradients come back in the weights' dtype"""
     from flashfftconv.hyena import project_in, project_out
     torch.manual_seed(0)
-    B, L, D = 2, 24, 8
+    L, D = 24, 8
     W = torch.randn(3 * D, D, requires_grad=True); Wo = torch.randn(D, D, requires_grad=True); bo = torch.randn(D, requires_grad=True)
     u = torch.randn(B, L, D).bfloat16().requires_grad_(True); y = torch.randn(B, D, L).bfloat16().requires_grad_(True)
     a = project_in(W, u); o = project_out(Wo, bo, y)

@@ -13,6 +13,7 @@ def _free_port():
 
 class OracleOps:
     """CPU stand-in for sharding._HipOps: the same four operations written with torch.fft + autograd."""
+    GENERIC_SLICES = True        # head groups of the pipelined exchange run on copies of the head range
 
     def __init__(self, N):
         self.N = N
@@ -80,8 +81,21 @@ def _worker_body(rank, world, port, H, q):
                                 and float(ug.grad[:, :s].abs().sum() + ug.grad[:, e:].abs().sum()) == 0.0)
     # ---- B-shard: batch rows split, k replicated; k_f all-gathered, dk_f reduce-scattered, dk all-gathered
     b0, b1 = rank * B // world, (rank + 1) * B // world
+    # spy on the collectives: the exchange mode must issue every one of them with async_op=True (waited for where the result is
+    # first needed, sharding._Pending), never synchronously in the middle of the compute
+    issued = []
+    for name in ("all_gather_into_tensor", "reduce_scatter_tensor", "all_gather", "all_reduce"):
+        def make(fn, name):
+            def spy(*a, **kw):
+                issued.append((name, bool(kw.get("async_op", False))))
+                return fn(*a, **kw)
+            return spy
+        setattr(dist, name, make(getattr(dist, name), name))
     for gated in (False, True):
-        for mode in ("allgather_kf", "recompute"):
+        for mode in ("allgather_kf", "allgather_kf/2groups", "recompute"):
+            ngroups = 2 if mode.endswith("2groups") else 1
+            tagmode, mode = mode.replace("/", "_"), mode.split("/")[0]
+            issued.clear()
             leaves = [t.clone().requires_grad_(True) for t in ((u, k, pre, post) if gated else (u, k))]
             ref = ref_fft_conv(leaves[0] * leaves[2], leaves[1], N) * leaves[3] if gated else ref_fft_conv(leaves[0], leaves[1], N)
             ref.backward(dout)
@@ -89,13 +103,16 @@ def _worker_body(rank, world, port, H, q):
             gl = [t[b0:b1].clone().requires_grad_(True) for t in (pre, post)] if gated else []
             ops = OracleOps(N)
             conv = BatchShardedFFTConv((lambda a, b, p=None, q=None: ops.conv(a, ops.kernel_fft(b), p, q)) if mode == "recompute" else None,
-                                       mode=mode, ops=ops if mode == "allgather_kf" else None)
+                                       mode=mode, ops=ops if mode == "allgather_kf" else None, groups=ngroups)
             if mode == "recompute":
                 # differentiable stand-in for the module: oracle conv through autograd
                 conv.conv = (lambda a, b, p=None, q=None: (ref_fft_conv(a * p, b, N) * q) if p is not None else ref_fft_conv(a, b, N))
             yl = conv(ul, kl, *gl)
             yl.backward(dout[b0:b1])
-            tag = f"bshard_{mode}_{'gated' if gated else 'plain'}"
+            tag = f"bshard_{tagmode}_{'gated' if gated else 'plain'}"
+            if mode == "allgather_kf":
+                # per head group: k_f all-gather, dk_f reduce(-scatter), dk all-gather -- all asynchronous
+                ok[tag + "_async"] = len(issued) == 3 * ngroups and all(a for _, a in issued)
             ok[tag + "_out"] = torch.allclose(yl, ref[b0:b1].detach(), atol=1e-4)
             ok[tag + "_du"] = torch.allclose(ul.grad, leaves[0].grad[b0:b1], atol=1e-4)
             ok[tag + "_dk"] = torch.allclose(kl.grad, leaves[1].grad, atol=1e-3)          # FULL gradient on every rank

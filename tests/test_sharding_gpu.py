@@ -65,8 +65,9 @@ def _body(rank, world, port, q):
         # ---- B-shard: k_f all-gather / dk_f reduce-scatter (fused sizes), recompute + all-reduce (big sizes)
         b0, b1 = rank * B // world, (rank + 1) * B // world
         bv = [u[b0:b1].clone().requires_grad_(True), k.clone().requires_grad_(True)] + [g[b0:b1].clone().requires_grad_(True) for g in gates]
-        for mode in (("allgather_kf", "recompute") if N <= 32768 else ("allgather_kf",)):
-            bs = BatchShardedFFTConv(mod, mode=mode)
+        # "/2g": the head-group pipeline (two groups; every launch on an in-place head range, collectives in flight between them)
+        for mode in (("allgather_kf", "allgather_kf/2g", "recompute") if N <= 32768 else ("allgather_kf", "allgather_kf/2g") if N <= 131072 else ("allgather_kf",)):
+            bs = BatchShardedFFTConv(mod, mode=mode.split("/")[0], groups=2 if mode.endswith("/2g") else 1)
             yl = bs(*bv)
             # bitwise where a pair meets the same kernel code alone as in the full batch; the inner sizes 8192 / 16384 run two
             # pairs of a head in lock-step when they have them (Body::inner_tile2x) and one pair alone otherwise: same

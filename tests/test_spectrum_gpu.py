@@ -48,6 +48,15 @@ def _call_pair(N, B, H, L, dtype, gated):
         _lib.check(lib.ffc_conv_bwd_z(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o1[0]), g(o1[1]), P(o2), P(ws1), P(z), B, H, L,
                                       0, 0, 0, 0, 0, 0, 0, sp()), "bwd_z")
         assert rel(o2, o0[2]) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+        # ffc_conv_bwd_zy: dpost = dout * y_raw written by the kernel's dout row load -- bit for bit the elementwise product
+        # (fp32 product, rounded once), du / dpregate / dk_f unchanged by the side product
+        o3 = [torch.full_like(u, 17.0) for _ in range(3)]; ws3 = torch.empty_like(ws0)
+        _lib.check(lib.ffc_conv_bwd_zy(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o3[0]), P(o3[1]), P(o3[2]), P(ws3), P(z), P(yraw),
+                                       B, H, L, 0, 0, 0, 0, 0, 0, 0, sp()), "bwd_zy")
+        assert torch.equal(o3[2], o1[2]), "fused dpostgate != dout * y_raw"
+        assert torch.equal(o3[0], o1[0]) and torch.equal(o3[1], o1[1]), "du / dpregate changed by the fused dpostgate"
+        nsl = lib.ffc_dkf_slab_count(plan.handle, B, H) * H * plan.kf_elems * 2 * 4
+        assert torch.equal(ws3[:nsl], ws1[:nsl]), "dk_f sums changed by the fused dpostgate"
     dk0 = torch.empty(H, L, device="cuda"); dk1 = torch.empty(H, L, device="cuda")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws0), B, H, L, P(dk0), sp()), "dk")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws1), B, H, L, P(dk1), sp()), "dk")
