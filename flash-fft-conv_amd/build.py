@@ -89,8 +89,12 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
         checked = f in AGPR_CHECKED
         src = os.path.join(CSRC, f)
         out = os.path.join(obj_dir, f + ".o")
-        asm = os.path.join(obj_dir, os.path.splitext(f)[0] + "-hip-amdgcn-amd-amdhsa-gfx950.s")
-        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time) or (checked and not os.path.exists(asm)):
+        stem = os.path.splitext(f)[0]
+        asm = os.path.join(obj_dir, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        marker = os.path.join(obj_dir, stem + ".agpr_ok")       # the check passed for this object (the 50 MB of temporaries are not kept)
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), hdr_time) or (checked and not os.path.exists(marker)):
+            if os.path.exists(marker):
+                os.remove(marker)
             only = os.environ.get("FFC_VARIANT_ONLY")      # tuning builds: extra flags for one translation unit only
             fl = flags if (not only or f == only) else HIP_FLAGS
             cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + ["-c", "-x", "hip", src, "-o", out]
@@ -103,6 +107,11 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
                 except Exception:
                     os.remove(out)          # a failed check must not leave an object the next build would link
                     raise
+                open(marker, "w").write("ok\n")
+            if checked and not os.environ.get("FFC_KEEP_TEMPS"):      # -save-temps leaves ~50 MB per unit: every gpurun push carried them
+                for g in os.listdir(obj_dir):
+                    if g.startswith(stem + "-hip-") or g.startswith(stem + "-host-") or g.startswith(stem + ".hip-"):
+                        os.remove(os.path.join(obj_dir, g))
             return out, True
         return out, False
 

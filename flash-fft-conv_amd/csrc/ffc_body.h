@@ -255,6 +255,10 @@ struct Body {
     if constexpr (GEO::N3 != GEO::N2) copy_tab(tab + t.mat[2], GEO::L_F3, 6144);
     if constexpr (GEO::TW2_SEP) copy_tab(tab + t.twin2, GEO::L_TW2, 8192);
     if constexpr (GEO::HAS_SP) copy_tab(tab + t.mat_sp, GEO::L_FS, 3072);
+    if (B::wave() == 0) {      // tile counters of the dynamically scheduled phase B (64 bytes)
+      U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
+      B::lds_w128(B::lane() * 16 + GEO::L_DYN, z, B::lane() < 4);
+    }
     B::barrier();
   }
   static FFC_FN void lds_mat(Mat& m, int off) {
@@ -464,6 +468,57 @@ struct Body {
     rows_load<NC>(a, h, pq, un, X);
     rows_store<NC>(a, h, pq, un, X);
   }
+  // ------------------------------------------------------------------ input rows by LDS-DMA (round 4)
+  // 32-point outer digit, L <= N/2 (HALF): E rows n1 >= 16 of a wave's column slice are dead from the moment its phase C has
+  // read them until its next phase A writes them -- exactly the stretch in which the wave stores the current pair's output
+  // rows.  The next pair's input rows are copied into those dead rows by `global_load_lds_dword` (no VGPR destination, no
+  // LDS store pass, the copy runs under the output stores), in NATURAL layout (row 16 + n1, no bank swizzle: only phase A
+  // reads them, 4 bytes per lane with an 8-byte lane stride, conflict-free as it is).  One instruction = 64 lanes x 4 bytes =
+  // the wave's 128-column slice of one row of one plane: LDS-DMA destinations are lane-linear, and the slice is the largest
+  // piece of E that is both contiguous and owned by one wave (16-byte pieces would cover four waves' slices and need barriers).
+  // The backward kernels run on a 128-VGPR budget and cannot hold a register prefetch.
+  // In-place safety of phase A: tile pair tp reads dword tp of the 8-byte chunks of rows 16.., and writes dword tp of (swizzled)
+  // chunks of all rows: the dwords of the two tile pairs never meet.
+  static constexpr bool HAS_DMA = GEO::OUTER && GEO::N1 == 32 && GEO::S1 == 1;
+  static constexpr int DMA_ROW0 = GEO::N1 / 2;
+  static FFC_FN void rows_dma(const ConvArgs& a, int h, int pq, Unit un) {
+    if (a.stream) rows_dma_t<true>(a, h, pq, un);      // (one branch for the whole burst, not one per instruction)
+    else rows_dma_t<false>(a, h, pq, un);
+  }
+  template <bool NT>
+  static FFC_FN void rows_dma_t(const ConvArgs& a, int h, int pq, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+      const int b = 2 * pq + pl;
+      if (b >= a.B) continue;                                   // missing batch row: zero-filled by rows_dma_finish
+      const uint16_t* base = (const uint16_t*)a.u + row_off(b, true, a.sbu, h, a.L);
+#pragma unroll
+      for (int r = 0; r < GEO::N1 / 2; r++) {
+        if (r * GEO::Mi >= a.L) continue;                       // the whole row lies beyond L (wave-uniform)
+        i32 n = B::imin(lane * 2 + (r * GEO::Mi + un.wq * 128), a.L - 2);      // clamped: the tail is zeroed after the wait
+        B::template g2lds32<NT>(base, n >> 1, un.eb + pl * GEO::PLANE + (DMA_ROW0 + r) * (GEO::Mi * 2) + un.wq * 256);
+      }
+    }
+  }
+  // wait for the wave's own copies (the reads that follow are its own: no barrier needed), zero what lies beyond L / B
+  static FFC_FN void rows_dma_finish(const ConvArgs& a, int pq, Unit un) {
+    B::vm_wait0();
+    const i32 lane = B::opaque(B::lane());
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+      const bool ok = (2 * pq + pl) < a.B;
+#pragma unroll
+      for (int r = 0; r < GEO::N1 / 2; r++) {
+        if (ok && (r + 1) * GEO::Mi <= a.L) continue;           // fully valid row (wave-uniform): nothing to do
+        i32 n = lane * 2 + (r * GEO::Mi + un.wq * 128);
+        B::lds_w32p(lane * 4 + (un.eb + pl * GEO::PLANE + (DMA_ROW0 + r) * (GEO::Mi * 2) + un.wq * 256), B::uconst(0),
+                    B::pnot((n < a.L) && ok));
+      }
+    }
+    B::lds_fence();
+  }
+
   // inner-only sizes: per-lane batch row.  Element offset of (b,h,n) relative to tensor base fits
   // 32 bits in 16-byte units (launcher checks the tensor size).
   static FFC_FN U4 gload8_rows(const uint16_t* base, i32 b, int h, const ConvArgs& a, int64_t sb, i32 n, int fast, pred ok) {
@@ -776,12 +831,15 @@ struct Body {
   // (B::merge_lo / merge_hi = v_perm_b32), and the results go back as one v_cvt_pk(tile 2tp, tile 2tp+1) per row and plane
   // (the first tile's fp32 accumulators wait for the second tile's instead of a stash of packed halves).
   // No length masks: every E row this stage reads was written by rows_store, zero beyond L (HALF never reads rows >= 16).
-  template <bool FWD, bool HALF, bool RP = false>
+  // DIN: the input rows were copied by LDS-DMA into E rows 16.. in natural layout (rows_dma)
+  template <bool FWD, bool HALF, bool RP = false, bool DIN = false>
   static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
+    static_assert(!DIN || (FWD && HALF && HAS_DMA && !RP), "DMA input rows: forward stage of the half-empty 32-point digit");
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
     const i32 j = lane & 31, hi = lane >> 5;
     constexpr int ms_lim = (FWD && HALF && GEO::N1 == 32) ? 1 : 2;      // a whole K-step of dead rows (32-point digit)
+    i32 colr = hi * (4 * GEO::Mi * 2) + j * 8 + (un.eb + DMA_ROW0 * (GEO::Mi * 2) + w * 256);     // DIN: natural-layout read base
     // tile-local row R = 4*hi + c (c a compile-time constant with bit 2 clear) -> column set
     // s1 = c / N1 and E row rw = c % N1 + 4*hi.  e_off = row term + swizzled column term, so every
     // access below is (one of S1 lane-dependent bases) + immediate.
@@ -802,7 +860,7 @@ struct Body {
         for (int e = 0; e < 8; e++) {
           const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
           const int s1 = c / GEO::N1, rwc = c % GEO::N1;
-          i32 off = colb[s1] + (rwc * (GEO::Mi * 2) + 4 * tp);
+          i32 off = (DIN ? colr : colb[s1]) + (rwc * (GEO::Mi * 2) + 4 * tp);
           if (FWD && HALF && row_dead(c)) { rawr[ms][e] = B::uconst(0); rawi[ms][e] = B::uconst(0); continue; }
           rawr[ms][e] = B::lds_r32(off); rawi[ms][e] = B::lds_r32(off + GEO::PLANE);
         }
@@ -884,8 +942,9 @@ struct Body {
 
   // The forward/dx kernels take the tile-pair variant (fastest); the backward kernels, which run on the
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
-  template <bool FWD, bool HALF, bool RP = false>
+  template <bool FWD, bool HALF, bool RP = false, bool DIN = false>
   static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
+    if constexpr (DIN) { outer_stage_pair<FWD, HALF, RP, true>(L, un, s_fwd, ps); return; }
 #if defined(FFC_KO) && (FFC_KO & 8)
     return;
 #endif
@@ -1550,12 +1609,34 @@ struct Body {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2_sp(a, hk, un.wq * GEO::TPW + tt, R, Fs, un);
         } else if constexpr (GEO::N3 == GEO::N2) {
+#ifndef FFC_DYN_TILES
+#define FFC_DYN_TILES 0
+#endif
+#if FFC_DYN_TILES
+          // Dynamically scheduled phase B (round 4): the unit's NT tiles are handed out in pairs through an LDS counter instead of
+          // four fixed tiles per wave.  The two waves of a SIMD never run at the same rate (issue is oldest-first: profiles/
+          // r03_wave_priority.txt), so with a fixed split one of them finishes early and waits at the barrier; here the faster
+          // wave simply takes more tiles and all waves reach the barrier within one tile pair of each other.  Results do not
+          // depend on which wave computes a tile.  Two counters per unit, used alternately: the one the previous iteration used
+          // is reset here, behind the barrier that every wave passed after it last touched it.
+          uint8_t* const zsl = SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr;
+          const int cnt = GEO::L_DYN + (u * 2 + (it & 1)) * 4;
+          if (un.wq == 0) B::lds_w32(B::lane() * 0 + (GEO::L_DYN + (u * 2 + ((it + 1) & 1)) * 4), B::uconst(0));
+          int tt = B::lds_fetch_add(cnt, 2);
+#pragma unroll 1
+          while (tt < GEO::NT) {
+            const int nxt = B::lds_fetch_add(cnt, 2);
+            inner_tile2<RP, SZ>(a, hk, tt, R, un, ps, zsl);
+            tt = nxt;
+          }
+#else
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) {
             if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
             inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
                                 SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr);
           }
+#endif
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);

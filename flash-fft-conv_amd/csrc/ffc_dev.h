@@ -172,6 +172,25 @@ struct DevB {
     return U2{v.x, v.y};
   }
   static FFC_FN void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+  // LDS-DMA (global_load_lds_dword): lane's dword `dw` of base -> LDS[lds_off + 4 * lane]; lds_off is wave-uniform (M0).
+  // No VGPR destination; completion is counted by vmcnt (vm_wait0).  nt: streaming policy (rows read once).
+  template <bool NT>
+  static FFC_FN void g2lds32(const void* base, i32 dw, int lds_off) {
+    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)((const uint32_t*)base + dw);
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(ffc_smem + lds_off);
+    if constexpr (NT) __builtin_amdgcn_global_load_lds(g, l, 4, 0, 2);
+    else __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+  }
+  // wave-uniform fetch-and-add on an LDS word: one lane performs it, the old value is broadcast
+  static FFC_FN int lds_fetch_add(int off, int v) {
+    int r = 0;
+    if ((threadIdx.x & 63) == 0)
+      r = __hip_atomic_fetch_add((int*)__builtin_assume_aligned(ffc_smem + off, 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(r);
+  }
+  static FFC_FN void vm_wait0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+  static FFC_FN void lds_w32p(i32 off, u32 v, pred p) { if (p) *(uint32_t*)(ffc_smem + off) = v; }
+  static FFC_FN pred pnot(pred p) { return !p; }
   static FFC_FN u32 uconst(uint32_t c) { return c; }
   static FFC_FN i32 mul24(i32 a, i32 b) { return __mul24(a, b); }
   static FFC_FN unsigned long long clock() { return __builtin_amdgcn_s_memtime(); }

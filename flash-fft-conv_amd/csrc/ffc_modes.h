@@ -829,6 +829,12 @@ struct Modes : Body<B, GEO, DT> {
       // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
       // DESIGN.md section 7)
       const bool have_z = ZM < 0 ? d.zin != nullptr : ZM == 1;
+      // input rows of dout by LDS-DMA into the dead half of the exchange buffer (Body::rows_dma): saved-spectra form of the
+      // HALF kernels with a 32-point outer digit, plain rows (no gate multiply / side product on the way in), 16-byte-aligned
+      // tensors; tuning flag 8 (FFC_FLAGS) keeps the register path for A/B runs
+      constexpr bool DMA_OK = BD::HAS_DMA && HALF && !RP && ZM != 0;
+      const bool dma = DMA_OK && have_z && a.fast && !ad.pregate && !ad.aux_in && !dpost_tf && !(a.flags & 8);
+      if constexpr (DMA_OK) { if (dma && p0 + u < p1) BD::rows_dma(ad, h, p0 + u, un); }
       // wave priority by progress between two barriers (Body::outer_jobs has the measurements): row loads 1, phase A 0, the
       // tile loops 3 then 1 (2 for the second-dispatched wave of the SIMD), phase C 3, stores 2
       const bool second = wv >= 4;
@@ -877,12 +883,24 @@ struct Modes : Body<B, GEO, DT> {
           }
           FFC_BTICK(5)
           if (act) {
-            if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
-            else BD::template rows_in<NCX>(ad, h, p, un);
-            B::lds_fence();
-            FFC_BTICK(6)
-            FFC_BPRIO(0)
-            BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+            bool done = false;
+            if constexpr (DMA_OK) {
+              if (dma) {      // the rows were requested behind the previous pair's phase C (or in the prologue)
+                BD::rows_dma_finish(ad, p, un);
+                FFC_BTICK(6)
+                FFC_BPRIO(0)
+                BD::template outer_stage<true, HALF, RP, true>(a.L, un, a.s_fwd, ps);
+                done = true;
+              }
+            }
+            if (!done) {
+              if constexpr (RP) BD::template rows_in_rp<NCX>(ad, h, p, un, ps);
+              else BD::template rows_in<NCX>(ad, h, p, un);
+              B::lds_fence();
+              FFC_BTICK(6)
+              FFC_BPRIO(0)
+              BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+            }
             FFC_BTICK(7)
           }
         } else {
@@ -958,6 +976,8 @@ struct Modes : Body<B, GEO, DT> {
           BD::template outer_stage<false, HALF, RP>(a.L, un, 1.0f, ps);
           B::lds_fence();
           FFC_BTICK(11)
+          // the next pair's dout rows into E rows 16.. (dead: phase C has read them), in flight under the du stores below
+          if constexpr (DMA_OK) { if (dma && p + GEO::UPW < p1) BD::rows_dma(ad, h, p + GEO::UPW, un); }
           FFC_BPRIO(2)
           if constexpr (RP) {
             BD::template rows_out_rp<NCX>(ao, h, p, un, ps);

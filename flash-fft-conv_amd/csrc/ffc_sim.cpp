@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -54,6 +55,7 @@ struct WgCtx {
 static thread_local WgCtx* g_wg = nullptr;
 static thread_local int g_wave = 0;
 static thread_local Vec<float> g_agpr[128];   // per-wave accumulation registers (DevB: a0..a127)
+static std::atomic<long> g_dma_count{0};      // LDS-DMA instructions executed (tests: the path under test really ran)
 
 static inline float dt_to_f32(int DT, uint16_t h) { return DT == DT_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
 static inline uint16_t f32_to_dt(int DT, float f) { return DT == DT_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
@@ -182,6 +184,19 @@ struct SimB {
     return r;
   }
   static void lds_fence() {}
+  // LDS-DMA model: executed at issue (the simulator has no asynchronous memory pipe; the ordering rules -- vmcnt before the
+  // wave's own reads -- are the device code's business)
+  template <bool NT>
+  static void g2lds32(const void* base, const i32& dw, int lds_off) {
+    g_dma_count++;
+    for (int i = 0; i < 64; i++) { chk(lds_off + 4 * i, 4); memcpy(L() + lds_off + 4 * i, (const uint32_t*)base + dw.v[i], 4); }
+  }
+  static void vm_wait0() {}
+  static int lds_fetch_add(int off, int v) { chk(off, 4); return __atomic_fetch_add((int*)(L() + off), v, __ATOMIC_SEQ_CST); }
+  static void lds_w32p(const i32& off, const u32& v, const pred& p) {
+    for (int i = 0; i < 64; i++) if (p.v[i]) { chk(off.v[i], 4); memcpy(L() + off.v[i], &v.v[i], 4); }
+  }
+  static pred pnot(const pred& p) { pred r; for (int i = 0; i < 64; i++) r.v[i] = !p.v[i]; return r; }
   static i32 mul24(const i32& a, const i32& b) { return a * b; }
   static unsigned long long clock() { return 0; }
   template <int P> static void setprio() {}
@@ -331,6 +346,11 @@ static void sim_conv_t(const ConvArgs& a) {
           }
         }
         if constexpr (GEO::OUTER) {       // the launcher's HALF variant
+          if (a.zsave) {                  // spectrum-saving training forward (ffc_conv_fwd_z)
+            if ((GEO::N1 / 2) * GEO::Mi >= a.L) Body<SimB, GEO, DT>::template conv<true, true>(a, h, c);
+            else Body<SimB, GEO, DT>::template conv<false, true>(a, h, c);
+            return;
+          }
           if ((GEO::N1 / 2) * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
         }
         Body<SimB, GEO, DT>::conv(a, h, c);
@@ -471,6 +491,11 @@ int ffcsim_plan_info(int N, int dtype, int* nt, double* s_fwd, double* s_k, int3
 // Same contract as ffc_conv_fwd (include/flashfftconv_hip.h) but on host memory.
 static int g_sparse_rows = 0;
 void ffcsim_set_sparse(int rows) { g_sparse_rows = rows; }      // next ffcsim_conv_fwd calls run the frequency-sparse variant
+// spectrum buffer ([H][npair][N] complex dtype pairs) / pre-postgate output of the NEXT ffcsim_conv_fwd (written) and
+// ffcsim_conv_bwd (read) calls: the ffc_conv_fwd_z / ffc_conv_bwd_z(y) pair.  Fused single-pass sizes >= 4096.  flags: ConvArgs::flags.
+static void* g_z = nullptr; static void* g_yraw = nullptr; static int g_flags = 0;
+void ffcsim_set_z(void* z, void* yraw, int flags) { g_z = z; g_yraw = yraw; g_flags = flags; }
+long ffcsim_dma_count() { return g_dma_count.exchange(0); }
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
                     void* y, int B, int H, int L, int conj_kf) {
   HostPlan p;
@@ -485,6 +510,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.fast = (L % 8 == 0) && !g_force_slow;
   a.R = p.R;
   a.sparse = g_sparse_rows;
+  if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
   return dispatch<ConvRun>(N, dtype, a);
 }
 
@@ -611,6 +637,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.fast = (L % 8 == 0) && !g_force_slow;
   a.R = p.R;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
+  if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
   int rc = dispatch<BwdRun>(N, dtype, d);

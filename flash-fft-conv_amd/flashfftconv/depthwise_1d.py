@@ -1,7 +1,16 @@
 """FlashDepthWiseConv1d for MI355X (drop-in for reference flashfftconv/depthwise_1d.py:7-55)."""
+import os
 import torch
 
 from . import _lib
+
+# The reference's BLH backward returns the weight gradient with the WRONG memory layout: it computes dk as (d, k) and hands it
+# back as `.view({k, d})` -- a reinterpretation, not a transpose (csrc/flashfftconv/conv1d/conv1d_bwd_cuda_blh.cu:115) -- so
+# `weights.grad` (k, d) of an is_bhl=False module holds the (d, k)-ordered numbers, and its own test compares
+# `weights.grad.view(d, k)` (tests/test_conv1d.py:220).  This package returns the gradient OF the (k, d) parameter.
+# FFC_REF_BLH_GRAD_LAYOUT=1 reproduces the reference's layout (tests/test_reference_verbatim_gpu.py sets it to run the
+# reference's test file unmodified).
+_REF_BLH_GRAD_LAYOUT = os.environ.get("FFC_REF_BLH_GRAD_LAYOUT", "0") == "1"
 
 _DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
@@ -43,6 +52,8 @@ class _Conv1dFn(torch.autograd.Function):
         _lib.check(_lib.lib().ffc_conv1d_bwd(_lib.ptr(dout), _lib.ptr(x), _lib.ptr(weights), _lib.ptr(du), _lib.ptr(dw),
                                              _lib.ptr(db), _DT[x.dtype], _DT[weights.dtype], B, D, L, K, ctx.padding,
                                              int(ctx.is_bhl), _lib.stream_ptr()), "ffc_conv1d_bwd")
+        if _REF_BLH_GRAD_LAYOUT and not ctx.is_bhl:
+            dw = dw.t().contiguous().view(K, D)
         return du, dw.to(weights.dtype), db.to(bias.dtype), None, None
 
 

@@ -26,7 +26,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build_sim())
+        _lib = ctypes.CDLL(os.environ.get("FFC_SIM_LIB") or build_sim())      # FFC_SIM_LIB: a hand-built variant (e.g. -DFFC_DYN_TILES=1)
     return _lib
 
 
@@ -191,3 +191,28 @@ def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchun
     assert lib().ffcsim_kernel_ifft_grad(N, dtype, p(ws), nslab, H, Lk, p(dk)) == 0
     sim_bwd.dpost = dpost          # fused sizes >= 4096 only (N <= 1024 leaves zeros: the library runs the forward kernel)
     return du, dpre, dk
+
+
+def sim_fwd_bwd_z(N, dtype, u_bits, dout_bits, kf_bits, pre=None, post=None, nchunk=1, flags=0):
+    """the spectrum-saving pair on the simulator (ffc_conv_fwd_z -> ffc_conv_bwd_z / _zy): forward output, du, dpre, dpost bits and
+    the fp32 dk_f slabs.  flags: ConvArgs::flags of the backward (8 = no LDS-DMA input rows)."""
+    B, H, L = u_bits.shape
+    nt, _, _, _ = plan_info(N, dtype)
+    upw = lib().ffcsim_upw(N)
+    z = np.zeros(((B + 1) // 2) * H * N * 2, np.uint16)
+    yraw = np.zeros_like(u_bits) if pre is not None else None
+    y = np.zeros_like(u_bits)
+    lib().ffcsim_set_z(p(z), p(yraw), 0)
+    try:
+        assert lib().ffcsim_conv_fwd(N, dtype, p(u_bits), p(kf_bits), p(pre), p(post), p(y), B, H, L, 0) == 0
+        ws = np.full(max(nchunk, 1) * upw * H * nt * 2048, np.nan, np.float32)
+        du = np.zeros_like(u_bits)
+        dpre = np.zeros_like(u_bits) if pre is not None else None
+        dpost = np.zeros_like(u_bits) if pre is not None else None
+        lib().ffcsim_set_z(p(z), p(yraw), flags)
+        nslab = lib().ffcsim_conv_bwd(N, dtype, p(dout_bits), p(u_bits), p(kf_bits), p(pre), p(post), p(du), p(dpre), p(dpost),
+                                      p(ws), B, H, L, nchunk)
+        assert nslab > 0, nslab
+    finally:
+        lib().ffcsim_set_z(None, None, 0)
+    return y, du, dpre, dpost, ws[: nslab * H * nt * 2048].copy()

@@ -1,5 +1,6 @@
 """Kernel logic on CPU: the SAME kernel body the GPU runs (ffc_body.h / ffc_modes.h) is executed by
 the 64-lane wave simulator (csrc/ffc_sim.cpp) and compared with the oracle."""
+import ctypes
 import numpy as np
 import pytest
 
@@ -321,3 +322,45 @@ def test_fft2048_inner_multipass(L, B, H, dt):
             assert rel(S.from_bits(dpre, dt), r[2]) < TOL[dt]
         dk2 = S.sim_dk(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), max(L - 4, 1), pre, post, nchunk=1)
         assert rel(dk2, r[1][:, :max(L - 4, 1)]) < 1.5 * TOL[0]
+
+
+# ---------------------------------------------------------------- spectrum-saving pair (ffc_conv_fwd_z -> ffc_conv_bwd_z / _zy) and
+# the LDS-DMA input rows of its backward (Body::rows_dma: next pair's dout rows copied into the dead half of the exchange buffer)
+@pytest.mark.parametrize("N,L,B,H,nch,gated", [(32768, 16384, 5, 1, 1, False),      # 3 pairs per unit: prologue + 2 run-ahead copies, odd batch
+                                               (32768, 16376, 4, 1, 1, False),      # ragged fast path: tail of the last row zeroed
+                                               (32768, 9000, 2, 1, 1, False),       # rows beyond L skipped, partial row
+                                               (8192, 4096, 10, 1, 1, False),       # 4 units per workgroup, 2 waves per unit, ragged unit count
+                                               (8192, 4096, 6, 2, 2, True),         # gated: register path + dpost from the dout row load
+                                               (16384, 8192, 4, 1, 1, True),        # 16-point outer digit: no DMA path, side product only
+                                               (4096, 2048, 6, 1, 1, False)])
+@pytest.mark.parametrize("dt", [0])
+def test_saved_spectrum_backward_and_dma_rows(N, L, B, H, nch, gated, dt):
+    rng = np.random.default_rng(N + L + B)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    ub, db = S.to_bits(u, dt), S.to_bits(d, dt)
+    S.lib().ffcsim_dma_count.restype = ctypes.c_long
+    S.lib().ffcsim_dma_count()
+    y, du, dpre, dpost, ws = S.sim_fwd_bwd_z(N, dt, ub, db, kf, pre, post, nch, flags=0)
+    ndma = S.lib().ffcsim_dma_count()
+    y8, du8, dpre8, dpost8, ws8 = S.sim_fwd_bwd_z(N, dt, ub, db, kf, pre, post, nch, flags=8)      # 8: register path for the rows
+    assert S.lib().ffcsim_dma_count() == 0
+    # one copy per (batch row, E row < ceil(L / Mi), wave): 32-point outer digit, plain rows
+    want = (B * H * (-(-L // (N // 32))) * (N // 4096)) if (N in (8192, 32768) and not gated) else 0
+    assert ndma == want, (ndma, want)
+    assert np.array_equal(du, du8) and np.array_equal(ws, ws8), "LDS-DMA input rows change the result"
+    # against the recomputing kernel: du bit for bit (same arithmetic on the same spectrum of dout), dk to the spectrum's rounding
+    du0, dpre0, dk0 = S.sim_bwd(N, dt, db, ub, kf, L, pre, post, nch)
+    assert np.array_equal(du, du0)
+    nt, _, _, _ = S.plan_info(N, dt)
+    dk = np.full((H, L), np.nan, np.float32)
+    assert S.lib().ffcsim_kernel_ifft_grad(N, dt, S.p(ws), ws.size // (H * nt * 2048), H, L, S.p(dk)) == 0
+    assert rel(dk, dk0.astype(np.float64)) < 3e-3
+    r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(S.from_bits(du, dt), r[0]) < TOL[dt] and rel(dk, r[1]) < 1.5 * TOL[0]
+    if gated:
+        assert np.array_equal(dpre, dpre0)
+        assert rel(S.from_bits(dpost, dt), r[3]) < TOL[dt]
