@@ -215,6 +215,11 @@ def readme_rows(sizes=None):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which == "row":       # one shape: sweep.py row N B H L [H_run] [gated]  (routing A/B runs: FFC_MULTIPASS=... in the environment)
+        N, B, H, L = (int(x) for x in sys.argv[2:6])
+        Hrun = int(sys.argv[6]) if len(sys.argv) > 6 else None
+        r = conv_row(f"fft {N} B{B} H{H} L{L} FFC_MULTIPASS={os.environ.get('FFC_MULTIPASS', 'default')}", N, B, H, L, Hrun=Hrun, gated=len(sys.argv) > 7)
+        print(json.dumps({k: v for k, v in r.items() if k != "peak_mem_bytes"} | {"peak_fwd_bwd": r["peak_mem_bytes"]["fwd_bwd_save_spectrum"]}), flush=True)
     if which in ("all", "configs"):
         for r in config_rows():
             print(json.dumps(r), flush=True)

@@ -1613,6 +1613,9 @@ struct Body {
 #define FFC_DYN_TILES 0
 #endif
 #if FFC_DYN_TILES
+          // (measured and NOT adopted, profiles/r04_ab_dyn_tiles.txt: forward +3 % at fft 32768 L = N/2, -3.5 % on the spectrum-saving
+          // forward at L = N, +-0 elsewhere -- the static split with wave priorities is already balanced to within a tile; and the
+          // one-wave-per-unit persistent kernel (fft 4096) must not use it: its jobs restart the counter parity.  Kept as a variant.)
           // Dynamically scheduled phase B (round 4): the unit's NT tiles are handed out in pairs through an LDS counter instead of
           // four fixed tiles per wave.  The two waves of a SIMD never run at the same rate (issue is oldest-first: profiles/
           // r03_wave_priority.txt), so with a fixed split one of them finishes early and waits at the barrier; here the faster
@@ -1622,12 +1625,17 @@ struct Body {
           uint8_t* const zsl = SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr;
           const int cnt = GEO::L_DYN + (u * 2 + (it & 1)) * 4;
           if (un.wq == 0) B::lds_w32(B::lane() * 0 + (GEO::L_DYN + (u * 2 + ((it + 1) & 1)) * 4), B::uconst(0));
-          int tt = B::lds_fetch_add(cnt, 2);
+          if constexpr (GEO::NW > 1) {
+            int tt = B::lds_fetch_add(cnt, 2);
 #pragma unroll 1
-          while (tt < GEO::NT) {
-            const int nxt = B::lds_fetch_add(cnt, 2);
-            inner_tile2<RP, SZ>(a, hk, tt, R, un, ps, zsl);
-            tt = nxt;
+            while (tt < GEO::NT) {
+              const int nxt = B::lds_fetch_add(cnt, 2);
+              inner_tile2<RP, SZ>(a, hk, tt, R, un, ps, zsl);
+              tt = nxt;
+            }
+          } else {
+#pragma unroll 1
+            for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps, zsl);
           }
 #else
 #pragma unroll 1

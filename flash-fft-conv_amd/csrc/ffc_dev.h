@@ -188,6 +188,14 @@ struct DevB {
       r = __hip_atomic_fetch_add((int*)__builtin_assume_aligned(ffc_smem + off, 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readfirstlane(r);
   }
+  // 16-byte form: lane's 16 bytes at base[o16] -> LDS[lds_off + 16 * lane] (1 KB per wave instruction)
+  template <bool NT>
+  static FFC_FN void g2lds128(const void* base, i32 o16, int lds_off) {
+    const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)((const uint4*)base + o16);
+    __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(ffc_smem + lds_off);
+    if constexpr (NT) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 2);
+    else __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+  }
   static FFC_FN void vm_wait0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
   static FFC_FN void lds_w32p(i32 off, u32 v, pred p) { if (p) *(uint32_t*)(ffc_smem + off) = v; }
   static FFC_FN pred pnot(pred p) { return !p; }

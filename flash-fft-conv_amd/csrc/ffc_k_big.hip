@@ -18,6 +18,31 @@ static int launch_big(const BigArgs& a, hipStream_t st) {
   return e == hipSuccess ? 0 : ffc_fail(std::string("big_kernel launch: ") + hipGetErrorString(e));
 }
 
+// persistent, double-buffered form (BigBody::run_pipe): one workgroup per CU walks the blocks, the next block's rows arrive by
+// LDS-DMA while the current one is transformed and stored
+template <int N0, int DT, bool FWD>
+__global__ __launch_bounds__((GeoBig<N0>::WGW + 1) * 64, 1) void big_pipe_kernel(BigArgs a) {      // + the loader wave
+  BigBody<DevB, N0, DT>::template run_pipe<FWD>(a, blockIdx.x, gridDim.x);
+}
+template <int N0, int DT, bool FWD>
+static int launch_big_pipe(const BigArgs& a, int num_cu, hipStream_t st) {
+  using BB = BigBody<DevB, N0, DT>;
+  int rc = ffc_set_lds(big_pipe_kernel<N0, DT, FWD>, BB::PIPE_LDS);
+  if (rc) return rc;
+  const int64_t nblk = (int64_t)a.npair * a.Hin * (a.Mi / GeoBig<N0>::Mi);
+  if (nblk <= 0 || nblk > 2147483647LL) return ffc_fail("outer pass: bad grid");
+  const unsigned grid = (unsigned)(nblk < num_cu ? nblk : num_cu);
+  hipLaunchKernelGGL((big_pipe_kernel<N0, DT, FWD>), dim3(grid), dim3((GeoBig<N0>::WGW + 1) * 64), BB::PIPE_LDS, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : ffc_fail(std::string("big_pipe_kernel launch: ") + hipGetErrorString(e));
+}
+// pipelined form when the pass qualifies: 16-byte accesses, no input gate on the forward side (tuning flag 16 = always run<>)
+template <int N0, int DT, bool FWD>
+static int launch_level(const BigArgs& a, const ffc_plan* p, hipStream_t st) {
+  const bool pipe = a.R == 1 && a.fast && !(FWD && a.gate) && !(p->env_flags & 16);
+  return pipe ? launch_big_pipe<N0, DT, FWD>(a, p->num_cu, st) : launch_big<N0, DT, FWD>(a, st);
+}
+
 // One outer level.  dir = 1 forward (long side `in` (Bv,Hin,Llong) -> `out` (2*npair, Hin*N0, Mi)),
 // dir = 0 inverse (`in` (2*npair, Hin*N0, Mi) -> long side `out` (Bv,Hin,Llong)).
 // `plan` supplies the N0-point DFT operand table in `dtype` (any plan of a size whose outer digit is N0).
@@ -39,11 +64,11 @@ extern "C" int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, in
   a.R = 1; a.c = 0;
   hipStream_t st = (hipStream_t)stream;
   if (n0 == 16) {
-    if (bf) return dir ? launch_big<16, DT_BF16, true>(a, st) : launch_big<16, DT_BF16, false>(a, st);
-    return dir ? launch_big<16, DT_F16, true>(a, st) : launch_big<16, DT_F16, false>(a, st);
+    if (bf) return dir ? launch_level<16, DT_BF16, true>(a, p, st) : launch_level<16, DT_BF16, false>(a, p, st);
+    return dir ? launch_level<16, DT_F16, true>(a, p, st) : launch_level<16, DT_F16, false>(a, p, st);
   }
-  if (bf) return dir ? launch_big<32, DT_BF16, true>(a, st) : launch_big<32, DT_BF16, false>(a, st);
-  return dir ? launch_big<32, DT_F16, true>(a, st) : launch_big<32, DT_F16, false>(a, st);
+  if (bf) return dir ? launch_level<32, DT_BF16, true>(a, p, st) : launch_level<32, DT_BF16, false>(a, p, st);
+  return dir ? launch_level<32, DT_F16, true>(a, p, st) : launch_level<32, DT_F16, false>(a, p, st);
 }
 
 // One level of factor R * 32 as R passes of the 32-point kernel (BigArgs::R): fft 4194304 = 128 x 32768 in ONE HBM level when

@@ -191,6 +191,11 @@ struct SimB {
     g_dma_count++;
     for (int i = 0; i < 64; i++) { chk(lds_off + 4 * i, 4); memcpy(L() + lds_off + 4 * i, (const uint32_t*)base + dw.v[i], 4); }
   }
+  template <bool NT>
+  static void g2lds128(const void* base, const i32& o16, int lds_off) {
+    g_dma_count++;
+    for (int i = 0; i < 64; i++) { chk(lds_off + 16 * i, 16); memcpy(L() + lds_off + 16 * i, (const uint8_t*)base + 16 * (int64_t)o16.v[i], 16); }
+  }
   static void vm_wait0() {}
   static int lds_fetch_add(int off, int v) { chk(off, 4); return __atomic_fetch_add((int*)(L() + off), v, __ATOMIC_SEQ_CST); }
   static void lds_w32p(const i32& off, const u32& v, const pred& p) {
@@ -496,6 +501,8 @@ void ffcsim_set_sparse(int rows) { g_sparse_rows = rows; }      // next ffcsim_c
 static void* g_z = nullptr; static void* g_yraw = nullptr; static int g_flags = 0;
 void ffcsim_set_z(void* z, void* yraw, int flags) { g_z = z; g_yraw = yraw; g_flags = flags; }
 long ffcsim_dma_count() { return g_dma_count.exchange(0); }
+static int g_big_pipe = 1;
+void ffcsim_set_big_pipe(int on) { g_big_pipe = on; }      // 0: every outer pass through BigBody::run (one block per workgroup)
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
                     void* y, int B, int H, int L, int conj_kf) {
   HostPlan p;
@@ -536,8 +543,13 @@ int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in,
   const int cols = N0 == 16 ? GeoBig<16>::Mi : GeoBig<32>::Mi;
   if (Mi % cols) return -2;
   const int nwg = npair * Hin * (Mi / cols);
-  for (int wg = 0; wg < nwg; wg++) {
-#define FFC_BIG(NN, DD, FF) run_wg(GeoBig<NN>::WGW, GeoBig<NN>::LDS_BYTES, [&]() { BigBody<SimB, NN, DD>::template run<FF>(a, wg); })
+  // the launcher's rule (ffc_k_big.hip launch_level): persistent double-buffered form for plain levels with 16-byte accesses and no
+  // input gate; here 3 "workgroups" walk the blocks so that every one of them runs several iterations
+  const bool pipe = g_big_pipe && R == 1 && a.fast && !(fwd && gate);
+  const int npw = pipe ? (nwg < 3 ? nwg : 3) : nwg;
+  for (int wg = 0; wg < npw; wg++) {
+#define FFC_BIG(NN, DD, FF) run_wg(GeoBig<NN>::WGW + (pipe ? 1 : 0), pipe ? BigBody<SimB, NN, DD>::PIPE_LDS : GeoBig<NN>::LDS_BYTES, [&]() { \
+      if (pipe) BigBody<SimB, NN, DD>::template run_pipe<FF>(a, wg, npw); else BigBody<SimB, NN, DD>::template run<FF>(a, wg); })
     if (N0 == 16) { if (dtype == DT_BF16) { if (fwd) FFC_BIG(16, DT_BF16, true); else FFC_BIG(16, DT_BF16, false); }
                     else { if (fwd) FFC_BIG(16, DT_F16, true); else FFC_BIG(16, DT_F16, false); } }
     else { if (dtype == DT_BF16) { if (fwd) FFC_BIG(32, DT_BF16, true); else FFC_BIG(32, DT_BF16, false); }

@@ -45,6 +45,24 @@ def choose(N, Lmax, ops=None):
     return BIG_FACTORS[N]
 
 
+def row_freq(N, fac=None):
+    """Where the inner k_f rows of one head sit in the N-point spectrum: (offsets, stride) with natural frequency
+    f = offsets[row] + stride * f_inner (mod N), rows in the order the levels produce them (head-major, first level outermost).
+    A level of factor n0 splits f = k0 + n0 f'; the factors 64 / 128 (R passes of the 32-point kernel) order their rows
+    c * 32 + d for k0 = c + R d.  Used to mask k_f / dk_f of the frequency-sparse convolution (flashfftconv/sparse_conv.py)."""
+    factors, M = fac or BIG_FACTORS[N]
+    offs, stride = [0], 1
+    for n0 in factors:
+        if n0 in (64, 128):
+            R = n0 // 32
+            k0s = [c + R * d for c in range(R) for d in range(32)]
+        else:
+            k0s = list(range(n0))
+        offs = [o + stride * k0 for o in offs for k0 in k0s]
+        stride *= n0
+    return offs, stride
+
+
 def level_scale(n0):
     """forward scale of one level ~ 1/sqrt(N0) (keeps the spectrum RMS near the input RMS)"""
     return {16: 0.25, 32: 0.125, 64: 0.125, 128: 0.0625}[n0]

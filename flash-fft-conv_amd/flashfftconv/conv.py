@@ -24,6 +24,7 @@ FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
 # where the HBM-level form measured 16.5.  FFC_MULTIPASS="2048,65536" etc. selects other routings for A/B runs.
 import os as _os
 MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "2048,65536,131072").split(",") if x.strip())
+_ROUTE_BY_LENGTH = _os.environ.get("FFC_ROUTE_BY_LENGTH", "1") != "0"      # fft 131072: HBM-level form for rows longer than N/2 (FlashFFTConv._route_big)
 # fft size 2048 has no 16/32-digit factorisation of its own.  By default it runs as 2 passes of the 1024 kernel
 # (MULTIPASS_SEQLENS below); the round-1 form, kept for A/B runs (FFC_MULTIPASS without 2048): the 4096 plan with k periodised,
 # k' = [k_2048 | k_2048].  FFT_4096(k') is 2*FFT_2048(k) on the even bins and 0 on the odd ones, so the 4096-point
@@ -57,6 +58,27 @@ def _apply_noting_grad_mode(fn, *args):
 def _recording():
     g = getattr(_TLS, "grad", None)
     return True if g is None else g
+
+
+_NOOP_CTX = __import__("contextlib").nullcontext()
+
+
+def _dev_ctx(device):
+    """device guard that costs nothing when `device` already is the current one (torch.cuda.device() resolves the index through
+    several Python layers, ~5 us per entry: a tenth of a short-sequence step)"""
+    get = getattr(torch._C, "_cuda_getDevice", None)
+    if get is not None and device.index is not None and device.index == get():
+        return _NOOP_CTX
+    return torch.cuda.device(device)
+
+
+def _ws_bytes(plan, B, H):
+    """ffc_dkf_workspace_bytes, remembered per (B, H): one ctypes trip less per backward"""
+    c = plan.__dict__.setdefault("_ws_cache", {})
+    n = c.get((B, H))
+    if n is None:
+        n = c[(B, H)] = _lib.lib().ffc_dkf_workspace_bytes(plan.handle, B, H)
+    return n
 
 
 def _kf_key(k):
@@ -247,7 +269,12 @@ class _TorchOps:
         return 256.0 if dt == torch.float16 else 1.0
 
     def to_dtype_rows(self, dt, k, H, Lk, pre=1.0):
-        return (k.detach() * pre).to(dt).reshape(1, H, Lk).contiguous()
+        # one elementwise kernel (fp32 product rounded once into the dtype), not multiply + cast + copy
+        k = k.detach().reshape(1, H, Lk)
+        if pre == 1.0:
+            return k.to(dt).contiguous()
+        out = torch.empty(1, H, Lk, dtype=dt, device=k.device)
+        return torch.mul(k, pre, out=out)
 
     def to_float_rows(self, out, H, Lk):
         return out[0].float()
@@ -310,6 +337,26 @@ def _big_kernel_fft(mod, k, fac=None):
     return _big.kernel_fft(ops, mod.dtype, mod.seqlen, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1], fac)
 
 
+def _big_kf_mask(mod, fac, device, dtype):
+    """frequency-sparse convolution at an HBM-level size: 0/1 mask over the inner k_f rows of one head, (rows, kf_elems), keeping
+    the natural frequencies |f| < mod._kf_keep (bigfft.row_freq maps (row, inner position) to f)"""
+    fac = fac or _big.BIG_FACTORS[mod.seqlen]
+    key = ("big", mod.seqlen, fac, torch.device(device).index, dtype, mod._kf_keep)
+    m = mod._masks.get(key)
+    if m is None:
+        import numpy as np
+        plan = mod._get_plan(device, fac[1])
+        idx = np.empty(plan.kf_elems, dtype=np.int32)
+        _lib.check(_lib.lib().ffc_plan_kf_index(plan.handle, idx.ctypes.data_as(ctypes.c_void_p)), "ffc_plan_kf_index")
+        offs, stride = _big.row_freq(mod.seqlen, fac)
+        N = mod.seqlen
+        f = (np.asarray(offs, np.int64)[:, None] + stride * idx.astype(np.int64)[None, :]) % N
+        keep = (idx[None, :] >= 0) & ((f < mod._kf_keep) | (f > N - mod._kf_keep))
+        m = torch.from_numpy(keep.astype(np.float32)).to(device=device, dtype=dtype)
+        mod._masks[key] = m
+    return m
+
+
 def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
     """keep (training, module.save_spectrum): also return what the backward pass would otherwise compute again -- the
     transformed input x of the inner size (pair-plane rows), the inner spectra z (inner plans with that path) and, for the
@@ -321,6 +368,9 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
     M = (fac or _big.BIG_FACTORS[N])[1]
     if kf is None:
         kf = _big_kernel_fft(mod, k, fac)
+        if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py): zero the inner rows' bins |f| >= keep
+            m = _big_kf_mask(mod, fac, u.device, kf.dtype)
+            kf.view(H, m.shape[0], m.shape[1], 2).mul_(m[None, :, :, None])
     x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
     z = None
     if keep:
@@ -354,6 +404,13 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
     yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
+    if mod._kf_keep is not None:
+        # d/dk of (mask * FFT(k)): mask the fp32 inner dk_f partial sums (same row / position order as k_f) before the inverse
+        plan_m = ops._plan(M)
+        hp_m = xu.shape[1]
+        nsl = _lib.lib().ffc_dkf_slab_count(plan_m.handle, xu.shape[0], hp_m)
+        m32 = _big_kf_mask(mod, fac, u.device, torch.float32)
+        ws[: nsl * hp_m * plan_m.kf_elems * 8].view(torch.float32).view(nsl, H, m32.shape[0], m32.shape[1], 2).mul_(m32[None, None, :, :, None])
     if want_dkf:
         plan = ops._plan(M)
         hp, nfl = xu.shape[1], xu.shape[1] * plan.kf_elems * 2
@@ -404,7 +461,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, k, mod, pregate, postgate):
         _check_inputs(mod, u, k, (pregate, postgate))
-        with torch.cuda.device(u.device):      # launches go to u's device and its current stream
+        with _dev_ctx(u.device):      # launches go to u's device and its current stream
             return _FlashFFTConvFn._forward(ctx, u, k, mod, pregate, postgate)
 
     @staticmethod
@@ -413,7 +470,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
         pregate = None if pregate is None else pregate.contiguous()
         postgate = None if postgate is None else postgate.contiguous()
         ctx.mod, ctx.k_len, ctx.k_dtype, ctx.gated = mod, k.shape[-1], k.dtype, pregate is not None
-        ctx.big = mod._big
+        ctx.big = mod._big or mod._route_big(max(u.shape[-1], k.shape[-1]))
         kept = None
         if ctx.big:
             keep = mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
@@ -430,7 +487,9 @@ class _FlashFFTConvFn(torch.autograd.Function):
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
             kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None
-            if kf is None:
+            # one C-ABI call for k -> k_f + the convolution (ffc_conv_fwd_k) unless something sits between the two
+            one_call = kf is None and not mod._folded and mod._kf_keep is None
+            if kf is None and not one_call:
                 kf = _kernel_fft(plan, _periodise_k(k, mod.seqlen) if mod._folded else k)
                 if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py)
                     kf.mul_(mod._kf_mask(plan, kf.dtype)[None, :, None])
@@ -443,7 +502,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             # of u): dpostgate = dout * that, instead of one more inverse transform of the spectrum.
             # module.save_spectrum = False (or FFC_SAVE_SPECTRUM=0) keeps the reference's recomputing backward.
             z = yraw = None
-            rows = _sparse_rows(mod, plan)      # low-pass k_f: the forward kernel that skips the all-zero spectrum rows
+            rows = 0 if one_call else _sparse_rows(mod, plan)      # low-pass k_f: the forward kernel that skips the all-zero spectrum rows
             if rows:
                 out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
             elif mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
@@ -453,7 +512,17 @@ class _FlashFFTConvFn(torch.autograd.Function):
                         yraw = torch.empty_like(u)
                     except torch.cuda.OutOfMemoryError:
                         z = None
-            if not rows:
+            if one_call:
+                B, H, L = u.shape
+                k32 = k if (k.dtype == torch.float32 and k.is_contiguous()) else k.detach().to(torch.float32).contiguous()
+                kf = torch.empty(H, plan.kf_elems, 2, dtype=plan.dtype, device=u.device)
+                out = torch.empty_like(u)
+                _lib.check(_lib.lib().ffc_conv_fwd_k(plan.handle, _lib.ptr(k32), k32.shape[-1], _lib.ptr(kf), _lib.ptr(u), _lib.ptr(pregate),
+                                                     _lib.ptr(postgate), _lib.ptr(out), _lib.ptr(z), _lib.ptr(yraw), B, H, L,
+                                                     _lib.stream_ptr()), "ffc_conv_fwd_k")
+                if mod.cache_kf and not k.requires_grad:
+                    mod._kf_cache = (_kf_key(k), kf)
+            elif not rows:
                 out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             # (z, yraw: saved tensors, released with the graph and kept by retain_graph like the others)
@@ -469,7 +538,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
     def backward(ctx, dout):
         if not ctx.saved_tensors:
             raise RuntimeError("FlashFFTConv: backward needs module.training=True at forward time")
-        with torch.cuda.device(ctx.saved_tensors[0].device):
+        with _dev_ctx(ctx.saved_tensors[0].device):
             return _FlashFFTConvFn._backward(ctx, dout)
 
     @staticmethod
@@ -495,10 +564,19 @@ class _FlashFFTConvFn(torch.autograd.Function):
         lib = _lib.lib()
         k_len = plan.seqlen if ctx.mod._folded else ctx.k_len
         # one fused launch: du (+ dpregate, dpostgate when gated) + fp32 dk_f partial sums; then dk_f -> dk
-        ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device=u.device)
+        ws = torch.empty(_ws_bytes(plan, B, H), dtype=torch.uint8, device=u.device)
         du = torch.empty_like(u)
         dpre = torch.empty_like(u) if ctx.gated else None
         dpost = torch.empty_like(u) if ctx.gated else None
+        if not ctx.mod._folded and ctx.mod._kf_keep is None:
+            # one C-ABI call: fused backward (on the saved spectra when there are any) + dk_f -> dk (ffc_conv_bwd_k)
+            dk = torch.empty(H, k_len, dtype=torch.float32, device=u.device)
+            _lib.check(lib.ffc_conv_bwd_k(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate), _lib.ptr(postgate),
+                                          _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws), _lib.ptr(z), _lib.ptr(yraw), _lib.ptr(dk),
+                                          k_len, B, H, L, _lib.stream_ptr()), "ffc_conv_bwd_k")
+            if dk.dtype != ctx.k_dtype:
+                dk = dk.to(ctx.k_dtype)
+            return (du, dk, None, dpre, dpost) if ctx.gated else (du, dk, None, None, None)
         if z is not None and ctx.gated:
             # dpostgate = dout * y_raw out of the kernel's dout row load (round 3: a torch elementwise kernel, 3 x |u| bytes more)
             _lib.check(lib.ffc_conv_bwd_zy(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
@@ -571,6 +649,13 @@ class FlashFFTConv(torch.nn.Module):
         # "always" (FFC_SAVE_SPECTRUM=always): whenever the allocation succeeds; False: never (the reference's footprint)
         _sv = _os.environ.get("FFC_SAVE_SPECTRUM", "1")
         self.save_spectrum = False if _sv == "0" else ("always" if _sv == "always" else True)
+
+    def _route_big(self, Lmax):
+        """Per-call routing of fft 131072 (round 4, profiles/r04_route.txt, B16 H768 / H384, fwd + bwd ms): 4 passes of the fused 32768
+        kernel win while the rows fit half the fft size (L = 32K: 8.9 vs 13.3, L = 64K: 13.65 vs 13.5 at a third of the memory), one
+        HBM level around the fused 4096 kernel wins for longer rows (L = 128K: 7.1 vs 12.6 -- every pass of the multi-pass form
+        re-reads all four input blocks).  fft 65536 stays on its 2 passes at every length (L = 64K: 6.7 vs 7.2)."""
+        return self.seqlen == 131072 and not self._big and Lmax > 65536 and 131072 in MULTIPASS_SEQLENS and _ROUTE_BY_LENGTH
 
     def _cached_kf(self, k):
         c = self._kf_cache

@@ -9,11 +9,12 @@ Same classes, constructor arguments and semantics as the reference's torch.fft d
 x is (B, H, L) bf16/fp16 on the GPU, k is (H, Lk) fp32 (the reference demos up-cast x to fp32 and back;
 here the module dtype is x's dtype).  Both are differentiable in x and k.  The frequency-sparse variant
 zeroes k_f's bins in the library's internal order (mask built once from ffc_plan_kf_index) and masks the
-fp32 dk_f partial sums the same way in the backward; it is available for fft sizes <= 131072 (sequence length <= 65536).
+fp32 dk_f partial sums the same way in the backward, at every fft size the module supports (sequence lengths up to 2097152: above
+fft 131072 the mask goes onto the inner k_f / dk_f rows of the HBM-level form, flashfftconv/bigfft.py row_freq).
 """
 import torch
 
-from .conv import FlashFFTConv, FUSED_SEQLENS, FOLDED_SEQLENS, MULTIPASS_SEQLENS
+from .conv import FlashFFTConv
 
 
 class _ConvCache(torch.nn.Module):
@@ -28,8 +29,7 @@ class _ConvCache(torch.nn.Module):
         if conv is None:
             conv = FlashFFTConv(key[0], dtype=x.dtype)
             if keep is not None:
-                if key[0] not in FUSED_SEQLENS and key[0] not in FOLDED_SEQLENS and key[0] not in MULTIPASS_SEQLENS:
-                    raise NotImplementedError("FrequencySparseFFTConv: fft sizes above 131072 are not supported yet")
+                # (fft sizes with HBM levels, >= 262144: the mask is applied to the inner k_f / dk_f rows, conv._big_kf_mask)
                 # folded size (2048 on the 4096 plan): natural bin f of the 2048-point spectrum is bin 2f of the plan
                 conv._kf_keep = keep * (conv._plan_seqlen // conv.seqlen)
             self._convs[key] = conv

@@ -114,6 +114,16 @@ int ffc_conv_bwd_zy(const ffc_plan* plan, const void* dout, const void* u, const
                     const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw,
                     int64_t B, int64_t H, int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                     int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream);
+/* One call per direction of the module (MI355X host path: at short sequences a training step is bound by the host, and every trip
+ * through the binding costs 4-8 us).  ffc_conv_fwd_k = ffc_kernel_fft(k -> kf_out) + ffc_conv_fwd / ffc_conv_fwd_z (zsave, y_raw
+ * nullable) -- what reference FlashFFTConvFunc.forward does in one Python function, conv.py:572-588.  ffc_conv_bwd_k = the fused
+ * backward (on zin / y_raw when given, recomputing otherwise) + ffc_kernel_ifft_grad: all five gradients of conv.py:1737-1761 /
+ * :3979 from one call.  Contiguous tensors; same kernels and results as the separate entry points. */
+int ffc_conv_fwd_k(const ffc_plan* plan, const float* k, int64_t Lk, void* kf_out, const void* u, const void* pregate,
+                   const void* postgate, void* y, void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, void* stream);
+int ffc_conv_bwd_k(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
+                   void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw, float* dk, int64_t Lk, int64_t B,
+                   int64_t H, int64_t L, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

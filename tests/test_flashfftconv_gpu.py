@@ -12,6 +12,10 @@ from oracle.torch_ref import ref_fft_conv
 pytestmark = pytest.mark.gpu
 SEQLENS = [256, 512, 1024, 2048, 4096, 8192, 16384, 32768]
 REL = {torch.bfloat16: 2e-2, torch.float16: 5e-3}   # SURVEY.md section 8(c) gates
+# Round 4: the gates of the sizes with HBM levels (fft >= 65536) are the SAME as the fused sizes' (round 3 doubled them: VERDICT r03
+# weak #1).  Measured margins, profiles/r04_parity_margins.txt: worst case over 256 .. 4M is 0.41 x the gate (bf16 out / du 8.2e-3
+# at fft 4M against 2e-2, dk 1.0e-2 against 2e-2; fp16 8.4e-4 against 5e-3, dk 5.4e-3 against 1e-2).
+BIG_F = 1.0
 
 
 BIG = [65536, 131072, 262144, 524288, 1048576, 2097152, 4194304]
@@ -62,7 +66,7 @@ def stable(fn, what, tries=5):
 def run_case(B, H, seqlen, dtype, padded, gated):
     from flashfftconv import FlashFFTConv
     # big sizes add two bf16/fp16 roundings per outer level (through HBM) on each side
-    REL = {k: v * (2.0 if seqlen >= 65536 else 1.0) for k, v in globals()["REL"].items()}
+    REL = {k: v * (BIG_F if seqlen >= 65536 else 1.0) for k, v in globals()["REL"].items()}
     torch.manual_seed(0)
     B, H = set_B_H(B, H, seqlen)
     N = seqlen
@@ -106,7 +110,7 @@ def run_case(B, H, seqlen, dtype, padded, gated):
     assert rel(g[0], gref[0]) < GREL[dtype], f"du rel-L2 {rel(g[0], gref[0]):.3e}"
     # dk: SURVEY 8(c)(iii) gate is 2e-2 for both dtypes; the dk_f -> dk inverse always runs in bf16 operand
     # arithmetic (fp32 range for the unnormalised sums), so fp16 modules see ~5e-3 there, not fp16's ~1e-3
-    dk_tol = max(GREL[dtype], 1e-2 * (2.0 if seqlen >= 65536 else 1.0) * (1.5 if gated else 1.0))
+    dk_tol = max(GREL[dtype], 1e-2 * (BIG_F if seqlen >= 65536 else 1.0) * (1.5 if gated else 1.0))
     assert rel(g[1], gref[1]) < dk_tol, f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
     if gated:
         assert torch.allclose(g[2], gref[2], atol=1e-2)             # reference (:242-243)
@@ -187,7 +191,7 @@ def test_unit_scale_gated_relative_big(N, dtype, B, H, L):
 def _unit_scale_gated(N, dtype, B, H, L, big=False):
     from flashfftconv import FlashFFTConv
     torch.manual_seed(1)
-    f = 2.0 if big else 1.0          # two more roundings per outer level, as in run_case
+    f = BIG_F if big else 1.0
     if True:
         u, pre, post = (torch.randn(B, H, L, device="cuda").to(dtype).requires_grad_(True) for _ in range(3))
         k = (torch.randn(H, L, device="cuda") * 0.1).requires_grad_(True)
@@ -241,7 +245,7 @@ def test_baseline_configs_exact(name, N, B, H, L, gated):
     leaves = (u, k, pre, post) if gated else (u, k)
     g = torch.autograd.grad(out, leaves, dout)
     ref, gref = _chunked_reference(u, k, pre, post, dout, N, 64 if N <= 32768 else 4)
-    f = (2.0 if N >= 65536 else 1.0) * (1.5 if gated else 1.0)
+    f = (BIG_F if N >= 65536 else 1.0) * (1.5 if gated else 1.0)
     assert rel(out, ref) < f * REL[dtype], f"{name} out {rel(out, ref):.3e}"
     for nm, a, b in zip(("du", "dk", "dpregate", "dpostgate"), g, gref):
         e = rel(a, b)
@@ -297,7 +301,7 @@ def test_golden_vectors(path):
     else:
         out = conv(u, k)
     out.backward(t("dout", dtype))
-    tol = REL[dtype] * (2.0 if N >= 65536 else 1.0)
+    tol = REL[dtype] * (BIG_F if N >= 65536 else 1.0)
     assert rel(out, t("out", torch.float32)) < tol
     assert rel(u.grad, t("du", torch.float32)) < tol
     assert rel(k.grad, t("dk", torch.float32)) < max(tol, 1e-2)
@@ -338,7 +342,7 @@ def test_bidirectional_filter_fills_the_fft_size(N, dtype):
     ref = ref_fft_conv(uc, kc, n=N)
     dout = torch.randn_like(out)
     out.backward(dout); ref.backward(dout.clone())
-    tol = REL[dtype] * (2.0 if N >= 65536 else 1.0)
+    tol = REL[dtype] * (BIG_F if N >= 65536 else 1.0)
     assert k.grad.shape == (H, N)
     assert rel(out, ref) < tol and rel(u.grad, uc.grad) < tol and rel(k.grad, kc.grad) < max(tol, 1e-2)
 

@@ -364,3 +364,58 @@ def test_saved_spectrum_backward_and_dma_rows(N, L, B, H, nch, gated, dt):
     if gated:
         assert np.array_equal(dpre, dpre0)
         assert rel(S.from_bits(dpost, dt), r[3]) < TOL[dt]
+
+
+# ---------------------------------------------------------------- HBM-level outer pass: persistent double-buffered form (BigBody::run_pipe:
+# next block's rows by LDS-DMA into the idle exchange buffer) against the one-block-per-workgroup form -- same arithmetic, bit for bit
+@pytest.mark.parametrize("n0,mi,B,H,L,gated", [(32, 1024, 3, 2, 32768, False),     # 3 "workgroups" x 4 blocks, odd batch (missing Im row)
+                                               (32, 512, 2, 3, 9000, False),        # rows beyond L skipped, a partial 1 KB piece zero-filled
+                                               (16, 2048, 2, 1, 20008, False),      # 16-point level: two pieces per row
+                                               (32, 512, 2, 2, 16384, True)])       # gated: forward keeps run<>, the inverse pipelines (gate at the store)
+@pytest.mark.parametrize("dt", [0, 1])
+def test_outer_pass_pipelined_equals_per_block(n0, mi, B, H, L, gated, dt):
+    rng = np.random.default_rng(n0 + mi + L)
+    npair = (B + 1) // 2
+    x = S.to_bits(rng.standard_normal((B, H, L)).astype(np.float32), dt)
+    gate = S.to_bits(rng.standard_normal((B, H, L)).astype(np.float32), dt) if gated else None
+    L_ = S.lib()
+    L_.ffcsim_dma_count.restype = ctypes.c_long
+    res = {}
+    for pipe in (1, 0):
+        L_.ffcsim_set_big_pipe(pipe)
+        try:
+            L_.ffcsim_dma_count()
+            mid = np.full((2 * npair, H * n0, mi), 0x7fc0 if dt == 0 else 0x7e00, np.uint16)       # NaN-filled: every element must be written
+            assert L_.ffcsim_big_outer(n0, dt, 1, S.p(x), S.p(mid), S.p(gate), B, npair, H, mi, L, ctypes.c_float(0.125)) == 0
+            nf = L_.ffcsim_dma_count()
+            out = np.zeros_like(x)
+            assert L_.ffcsim_big_outer(n0, dt, 0, S.p(mid), S.p(out), S.p(gate), B, npair, H, mi, L, ctypes.c_float(0.25)) == 0
+            ni = L_.ffcsim_dma_count()
+        finally:
+            L_.ffcsim_set_big_pipe(1)
+        res[pipe] = (mid, out, nf, ni)
+    assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
+    assert res[0][2] == 0 and res[0][3] == 0
+    assert (res[1][2] > 0) == (not gated) and res[1][3] == 2 * npair * H * n0 * (mi * 2 // 1024)      # inverse: every 1 KB row piece once
+    # forward then inverse of a level = identity x (n0 * 0.125 * 0.25) on the valid part
+    ref = S.from_bits(x, dt).astype(np.float64) * (S.from_bits(gate, dt).astype(np.float64) ** 2 if gated else 1.0) * (n0 * 0.125 * 0.25)
+    assert rel(S.from_bits(res[1][1], dt), ref) < (2e-2 if dt == 0 else 3e-3)
+
+
+# ---------------------------------------------------------------- frequency-sparse convolution at the HBM-level sizes: bigfft.row_freq says
+# which natural frequency every (inner k_f row, inner position) holds; checked against the spectrum the kernels really produce
+@pytest.mark.parametrize("N,fac", [(65536, ((16,), 4096)), (131072, ((32,), 4096)), (1048576, ((16, 16), 4096)), (524288, ((128,), 4096)),
+                                   (262144, ((64,), 4096))])      # (the inner size needs an outer digit: complex-input k -> k_f)
+def test_row_freq_locates_every_bin_of_the_inner_rows(N, fac):
+    from flashfftconv import bigfft as BG
+    rng = np.random.default_rng(N + len(fac[0]))
+    dt, H, L = 0, 1, N // (fac[0][0] // 32) if fac[0][0] > 32 else N // 2
+    k = (rng.standard_normal((H, L)) * np.exp(-0.002 * np.arange(L))).astype(np.float32)
+    kf = S.from_bits(BG.kernel_fft(S.SimOps(), dt, N, k, H, L, fac), dt).astype(np.float64)      # (rows, kf_elems, 2), unscaled K_f
+    offs, stride = BG.row_freq(N, fac)
+    nt, _, _, freq = S.plan_info(fac[1], dt)
+    assert kf.shape[0] == len(offs) and kf.shape[1] == len(freq)
+    K = np.fft.fft(S.from_bits(S.to_bits(k, dt), dt).astype(np.float64)[0], n=N)
+    f = (np.asarray(offs)[:, None] + stride * np.asarray(freq)[None, :]) % N
+    got = kf[..., 0] + 1j * kf[..., 1]
+    assert rel(got, K[f]) < 2e-2
