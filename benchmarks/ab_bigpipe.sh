@@ -1,4 +1,4 @@
-# A/B of the persistent double-buffered outer pass (BigBody::run_pipe; FFC_FLAGS bit 16 = one block per workgroup as in round 3),
+# A/B of the persistent double-buffered outer pass (BigBody::run_pipe; FFC_FLAGS bit 16 = pipelined; default = one block per workgroup as in round 3),
 # module level fwd / bwd ms of HBM-level sizes.  Run through gpurun.
 O=${1:-gpurun_out/bigpipe}; mkdir -p $O
 for spec in "262144 16 768 131072 384" "1048576 16 768 524288 96" "2097152 16 768 1048576 48" "4194304 1 16 1048576" "1048576 8 48 1048576 48"; do

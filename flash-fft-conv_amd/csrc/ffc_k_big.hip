@@ -36,10 +36,14 @@ static int launch_big_pipe(const BigArgs& a, int num_cu, hipStream_t st) {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : ffc_fail(std::string("big_pipe_kernel launch: ") + hipGetErrorString(e));
 }
-// pipelined form when the pass qualifies: 16-byte accesses, no input gate on the forward side (tuning flag 16 = always run<>)
+// The pipelined form is OPT-IN (tuning flag 16, FFC_FLAGS=16) for passes that qualify (16-byte accesses, no input gate on the forward
+// side): measured on MI355X it LOSES to run<> -- module level fwd / bwd ms at B16 H768, profiles/r04_ab_bigpipe.txt: fft 262144
+// 12.0 / 13.7 against 11.0 / 12.8, fft 1M 49.5 / 55.5 against 47.8 / 53.6 (a first version without the loader wave: 12.6 / 14.5).  Two
+// independent one-block workgroups per CU keep more of the HBM pipe busy than one workgroup that double-buffers.  Kept because the
+// GPU parity suite ran green on it and the next attempt (two pipelined workgroups of 32 KB blocks) starts from here.
 template <int N0, int DT, bool FWD>
 static int launch_level(const BigArgs& a, const ffc_plan* p, hipStream_t st) {
-  const bool pipe = a.R == 1 && a.fast && !(FWD && a.gate) && !(p->env_flags & 16);
+  const bool pipe = a.R == 1 && a.fast && !(FWD && a.gate) && (p->env_flags & 16);
   return pipe ? launch_big_pipe<N0, DT, FWD>(a, p->num_cu, st) : launch_big<N0, DT, FWD>(a, st);
 }
 

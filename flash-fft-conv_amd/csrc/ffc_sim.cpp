@@ -501,7 +501,7 @@ void ffcsim_set_sparse(int rows) { g_sparse_rows = rows; }      // next ffcsim_c
 static void* g_z = nullptr; static void* g_yraw = nullptr; static int g_flags = 0;
 void ffcsim_set_z(void* z, void* yraw, int flags) { g_z = z; g_yraw = yraw; g_flags = flags; }
 long ffcsim_dma_count() { return g_dma_count.exchange(0); }
-static int g_big_pipe = 1;
+static int g_big_pipe = 0;      // as in the library: opt-in
 void ffcsim_set_big_pipe(int on) { g_big_pipe = on; }      // 0: every outer pass through BigBody::run (one block per workgroup)
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
                     void* y, int B, int H, int L, int conj_kf) {

@@ -392,7 +392,7 @@ def test_outer_pass_pipelined_equals_per_block(n0, mi, B, H, L, gated, dt):
             assert L_.ffcsim_big_outer(n0, dt, 0, S.p(mid), S.p(out), S.p(gate), B, npair, H, mi, L, ctypes.c_float(0.25)) == 0
             ni = L_.ffcsim_dma_count()
         finally:
-            L_.ffcsim_set_big_pipe(1)
+            L_.ffcsim_set_big_pipe(0)
         res[pipe] = (mid, out, nf, ni)
     assert np.array_equal(res[1][0], res[0][0]) and np.array_equal(res[1][1], res[0][1])
     assert res[0][2] == 0 and res[0][3] == 0
