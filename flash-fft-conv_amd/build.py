@@ -34,10 +34,10 @@ def check_agpr(asm_path):
     kernel, reads, writes, bad = None, Counter(), Counter(), []
 
     def close():
-        # every accumulator is zeroed + updated (2 writes) and read for the update + the final store (2 reads);
-        # any other count is a compiler spill into the same register
+        # every accumulator is zeroed + updated (2 writes) and read for the update + the final store (2 reads), in the kernels
+        # with the dk tail (Modes::dk_tail) once more for it (3 reads); any other count is a compiler spill into the same register
         for idx in set(reads) | set(writes):
-            if reads[idx] != 2 or writes[idx] != 2:
+            if reads[idx] not in (2, 3) or writes[idx] != 2:
                 bad.append(f"{kernel}: a{idx} read {reads[idx]}x written {writes[idx]}x")
         reads.clear(); writes.clear()
 

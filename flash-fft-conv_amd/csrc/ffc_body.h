@@ -74,6 +74,12 @@ struct ConvArgs {
   const void* aux_in;
   void* aux_out;
   int64_t sbai, sbao;
+  // optional (round 4; ffc_conv_fwd_k, single-pass fft 32768, one chunk per head): k (H, kfuse_Lk) fp32.  The workgroup first
+  // transforms ITS head's filter into `kf` (Modes::kfft_head: the k -> k_f kernel's work for one head, then phase B reads the tiles
+  // the same wave stored), so the forward needs no separate k -> k_f launch.  kf stays an output: the backward pass reads it.
+  const float* kfuse_k;
+  int kfuse_Lk, kfuse_fast;
+  float kfuse_scale;       // s_k / s_fwd (KfArgs::scale; bf16 plans: prescale 1)
 };
 
 // One pass of a multi-pass size (fft size N = R * M, M = GEO::N = N1 * Mi; HostPlan::R).  With n = n0 M + n1 Mi + mi and

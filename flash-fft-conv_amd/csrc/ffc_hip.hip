@@ -161,44 +161,8 @@ int ffc_debug_peaks(double* copy_GBs, double* mfma_TFLOPs) {
   *copy_GBs = bc; *mfma_TFLOPs = bm;
   return 0;
 }
-// ---- one call per direction (round 4): at short sequences a step is bound by the host -- every trip through the
-// foreign-function layer costs 4-8 us -- so the module's forward enqueues k -> k_f and the convolution with ONE call, its backward the
-// fused backward kernel and the dk_f -> dk inverse with one.  Same kernels, same results as the separate entry points.
-int ffc_kernel_fft(const ffc_plan*, const float*, int64_t, int64_t, void*, void*);
-int ffc_conv_fwd_strided(const ffc_plan*, const void*, const void*, const void*, const void*, void*, int64_t, int64_t, int64_t, int,
-                         int64_t, int64_t, int64_t, int64_t, void*);
-int ffc_conv_fwd_z(const ffc_plan*, const void*, const void*, const void*, const void*, void*, void*, void*, int64_t, int64_t, int64_t,
-                   int64_t, int64_t, int64_t, int64_t, void*);
-int ffc_conv_bwd_gated(const ffc_plan*, const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*,
-                       int64_t, int64_t, int64_t, void*);
-int ffc_conv_bwd_z(const ffc_plan*, const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*,
-                   const void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, void*);
-int ffc_conv_bwd_zy(const ffc_plan*, const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*,
-                    const void*, const void*, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                    void*);
-int ffc_kernel_ifft_grad(const ffc_plan*, const void*, int64_t, int64_t, int64_t, float*, void*);
-// k (H, Lk) fp32 -> kf_out, then y = postgate * conv(u * pregate, k); zsave / y_raw as in ffc_conv_fwd_z (both nullable)
-int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, void* kf_out, const void* u, const void* pregate, const void* postgate,
-                   void* y, void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, void* stream) {
-  int rc = ffc_kernel_fft(p, k, H, Lk, kf_out, stream);
-  if (rc) return rc;
-  if (zsave) return ffc_conv_fwd_z(p, u, kf_out, pregate, postgate, y, zsave, y_raw, B, H, L, 0, 0, 0, 0, stream);
-  return ffc_conv_fwd_strided(p, u, kf_out, pregate, postgate, y, B, H, L, 0, 0, 0, 0, 0, stream);
-}
-// the module's whole backward: du (+ dpre, dpost) and dk (H, Lk) fp32; zin / y_raw: what ffc_conv_fwd_k saved (nullable: recompute)
-int ffc_conv_bwd_k(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
-                   void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw, float* dk, int64_t Lk, int64_t B,
-                   int64_t H, int64_t L, void* stream) {
-  int rc;
-  if (zin && y_raw && dpost)
-    rc = ffc_conv_bwd_zy(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, y_raw, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream);
-  else if (zin)
-    rc = ffc_conv_bwd_z(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream);
-  else
-    rc = ffc_conv_bwd_gated(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, B, H, L, stream);
-  if (rc) return rc;
-  return ffc_kernel_ifft_grad(p, ws, B, H, Lk, dk, stream);
-}
+// (ffc_conv_fwd_k / ffc_conv_bwd_k, the module's one call per direction, live next to the launchers they drive: ffc_k_conv.hip,
+// ffc_k_bwd.hip)
 int ffc_version(void) { return 101; }
 const char* ffc_last_error(void) { return g_err.c_str(); }
 

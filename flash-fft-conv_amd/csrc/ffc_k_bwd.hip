@@ -60,7 +60,8 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H);
 static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate,
                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
-                         int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream, const void* yraw = nullptr) {
+                         int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream, const void* yraw = nullptr,
+                         float* dk = nullptr, int64_t Lk = 0, bool* dk_done = nullptr) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
   if (yraw && (!zin || !dpost)) return ffc_fail("y_raw needs the saved spectra and a dpost output");
   if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
@@ -89,6 +90,14 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
   a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate && p->hp.R == 1) ? 1 : 0);    // see Body::STREAM_ROWS
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
+  // dk from the same launch (Modes::dk_tail): the workgroup owns all pairs of its head, single-pass fft 32768, bf16 plan
+  // (tuning flag 32 keeps the slab + ffc_kernel_ifft_grad pair)
+  if (dk && dk_done && a.nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && p->hp.dtype == DT_BF16 && !(p->env_flags & 32) &&
+      Lk > 0 && Lk <= p->hp.N) {
+    d.dk_out = dk; d.Lk = (int)Lk; d.dk_scale = (float)(1.0 / p->hp.s_fwd);
+    d.dk_fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+    *dk_done = true;
+  }
   d.dpost = (p->hp.N1 > 1 || yraw) ? dpost : nullptr;      // with y_raw every geometry writes dpost from its dout row load
   d.zin = zin;
   d.yraw = yraw;
@@ -148,4 +157,20 @@ extern "C" int ffc_conv_bwd_gated(const ffc_plan* p, const void* dout, const voi
                                   const void* postgate, void* du, void* dpre, void* dpost, void* ws, int64_t B, int64_t H,
                                   int64_t L, void* stream) {
   return ffc_conv_bwd_gated_strided(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream);
+}
+
+// The module's whole backward in one call: du (+ dpre, dpost) and dk (H, Lk) fp32; zin / y_raw: what ffc_conv_fwd_k saved (nullable:
+// recomputing kernel).  dk comes out of the backward launch itself where a workgroup owns its head (Modes::dk_tail), through the
+// fp32 slabs in ws + ffc_kernel_ifft_grad otherwise.
+extern "C" int ffc_kernel_ifft_grad(const ffc_plan* p, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);
+extern "C" int ffc_conv_bwd_k(const ffc_plan* p, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
+                              void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw, float* dk, int64_t Lk,
+                              int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!dk) return ffc_fail("null dk");
+  bool dk_done = false;
+  const void* yr = (zin && y_raw && dpost) ? y_raw : nullptr;
+  int rc = conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream, yr, dk, Lk,
+                         &dk_done);
+  if (rc || dk_done) return rc;
+  return ffc_kernel_ifft_grad(p, ws, B, H, Lk, dk, stream);
 }

@@ -37,7 +37,14 @@ __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) vo
     int h, chunk;
     if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
     stagger_start(a.flags);
-    BD::template conv<HALF, SZ, SP>(a, h, chunk);
+    if constexpr (GEO::UPW == 1 && !SP) {
+      // k -> k_f of this head first (ConvArgs::kfuse_k, one chunk per head): no separate launch for it
+      BD::setup_tables(a.tab, a.t);
+      if (a.kfuse_k) Modes<DevB, GEO, DT>::kfft_head(a, h);
+      BD::template conv_job<HALF, false, SZ, SP>(a, h, chunk);
+    } else {
+      BD::template conv<HALF, SZ, SP>(a, h, chunk);
+    }
   }
 }
 
@@ -185,7 +192,8 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
 }
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                          void* y, void* zsave, void* yraw, int sparse, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
-                         int64_t sb_post, int64_t sb_y, void* stream) {
+                         int64_t sb_post, int64_t sb_y, void* stream, const float* kfuse_k = nullptr, int64_t kfuse_Lk = 0,
+                         bool* kfuse_done = nullptr) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -211,6 +219,14 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = ffc_persist(p);
   a.R = p->hp.R;
+  // k -> k_f inside this launch (Modes::kfft_head): a workgroup owns its head, single-pass fft 32768, bf16 plan (fp16 plans
+  // prescale k: kept on the separate kernel); tuning flag 64 keeps the separate launch
+  if (kfuse_k && kfuse_done && a.nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && p->hp.dtype == DT_BF16 && !sparse &&
+      !(p->env_flags & 64) && kfuse_Lk > 0 && kfuse_Lk <= p->hp.N && H * kfuse_Lk < ((int64_t)1 << 31)) {
+    a.kfuse_k = kfuse_k; a.kfuse_Lk = (int)kfuse_Lk; a.kfuse_scale = (float)(p->hp.s_k / p->hp.s_fwd);
+    a.kfuse_fast = (kfuse_Lk % 4 == 0) && !((uintptr_t)kfuse_k & 15);
+    *kfuse_done = true;
+  }
   // every row is read / written exactly once per launch (multi-pass sizes re-read the rows in every pass: plain accesses)
   a.stream = p->env_stream >= 0 ? p->env_stream : (p->hp.R > 1 ? 0 : 1);
   return ffc_dispatch<ConvLaunch>(p->hp.N, p->hp.dtype, a, (hipStream_t)stream);
@@ -285,4 +301,29 @@ extern "C" int ffc_conv_fwd_prof(const ffc_plan* p, const void* u, const void* k
   hipLaunchKernelGGL((conv_prof_kernel<GEO, DT_BF16>), dim3(hpad * a.nchunk), dim3(512), GEO::LDS_BYTES, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : ffc_fail(hipGetErrorString(e));
+}
+
+// The module's forward in one call (see ffc_hip.hip for the backward's): k (H, Lk) fp32 -> kf_out, then y = postgate * conv(u *
+// pregate, k); zsave / y_raw as in ffc_conv_fwd_z (both nullable).  Where a workgroup owns its head the k -> k_f step runs inside
+// the convolution launch (Modes::kfft_head); otherwise ffc_kernel_fft first.
+extern "C" int ffc_kernel_fft(const ffc_plan* p, const float* k, int64_t H, int64_t Lk, void* kf, void* stream);
+extern "C" int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, void* kf_out, const void* u, const void* pregate,
+                              const void* postgate, void* y, void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!p || !k || !kf_out) return ffc_fail("null arg");
+  if (y_raw && ((uintptr_t)y_raw & 15)) return ffc_fail("y_raw must be 16-byte aligned");
+  // decide first whether the convolution launch can take the k -> k_f step (same rule as conv_fwd_impl applies below)
+  int nchunk = 0, ppc = 0;
+  if (B > 0 && H > 0) ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc, true);
+  const bool fuse = nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && p->hp.dtype == DT_BF16 && !(p->env_flags & 64) && Lk > 0 &&
+                    Lk <= p->hp.N && H * Lk < ((int64_t)1 << 31);
+  if (!fuse) {
+    int rc = ffc_kernel_fft(p, k, H, Lk, kf_out, stream);
+    if (rc) return rc;
+  }
+  bool done = false;
+  int rc = conv_fwd_impl(p, u, kf_out, pregate, postgate, y, zsave, zsave ? y_raw : nullptr, 0, B, H, L, 0, 0, 0, 0, 0, stream,
+                         fuse ? k : nullptr, Lk, &done);
+  if (rc) return rc;
+  if (fuse && !done) return ffc_fail("internal: the convolution launch did not take the k -> k_f step");
+  return 0;
 }

@@ -49,6 +49,14 @@ struct DkfArgs {
   // ffc_conv_fwd_z.  dpost = dout * yraw is then a side product of the dout row load (ConvArgs::aux_in) instead of an inverse
   // transform of the saved spectrum.
   const void* yraw;
+  // optional (round 4; fused backward only): dk (H, Lk) fp32 written by the SAME launch.  When a workgroup owns every pair of its
+  // head (nchunk == 1) its accumulation registers hold the head's whole dk_f at the end of the pair loop, so the inverse
+  // transform of Modes::dkifft can run right there, from the registers: no 256 KB fp32 slab per head written and read back, no
+  // second launch (config 2: 201 MB each way and 0.07 ms of a 1.28 ms step).  Single-pass fft 32768, bf16 plans (the dk
+  // inverse always runs on bf16 tables: the kernel's own); the launcher falls back to slab + dkifft otherwise.
+  float* dk_out;
+  int Lk, dk_fast;
+  float dk_scale;      // 1 / s_fwd (W carries s_fwd^2, tile_inv applies 1 / (N s_fwd))
 };
 
 struct DkArgs {
@@ -305,6 +313,33 @@ struct Modes : Body<B, GEO, DT> {
     }
   }
 
+  // k -> k_f of ONE head inside another kernel's workgroup (ConvArgs::kfuse_k: the forward kernel when the workgroup owns its
+  // head): the single-pass OUTER branch of kfft() for unit `h`.  The plan tables are in LDS already.  Ends with a barrier: the
+  // caller's row copies may overwrite the exchange buffer.
+  static FFC_FN void kfft_head(const ConvArgs& c, int h) {
+    static_assert(GEO::OUTER && GEO::UPW == 1, "kfft_head: one unit per workgroup");
+    KfArgs a{};
+    a.k = c.kfuse_k; a.kf = const_cast<void*>(c.kf); a.H = c.H; a.Lk = c.kfuse_Lk; a.scale = c.kfuse_scale; a.s_fwd = c.s_fwd;
+    a.prescale = 1.0f; a.fast = c.kfuse_fast;
+    Unit un;
+    un.wq = B::wave() % GEO::NW;
+    un.eb = 0;
+    k_rows_in(a, h, un);
+    B::lds_fence();
+    if ((GEO::N1 / 2) * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
+    else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
+    B::barrier();
+    InnerRegs R;
+    BD::load_inner(R, un);
+#pragma unroll 1
+    for (int tt = 0; tt < GEO::TPW; tt++) {
+      A16 re, im;
+      BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+      kf_store(a, h, un.wq * GEO::TPW + tt, re, im);
+    }
+    B::barrier();
+  }
+
   // ------------------------------------------------------------------ dk_f accumulation
   struct ZReg { u32 r[8], i[8]; };   // a spectrum tile as packed dtype pairs (plain dwords: no register-tuple constraint)
   static FFC_FN void z_pack(const A16& re, const A16& im, ZReg& z) {
@@ -554,6 +589,36 @@ struct Modes : Body<B, GEO, DT> {
       w_acc_reduce_tile<2>(slab, un.wq * GEO::TPW, u, un.wq, lane);
       w_acc_reduce_tile<3>(slab, un.wq * GEO::TPW, u, un.wq, lane);
     }
+  }
+  // ---- dk from the accumulation registers (DkfArgs::dk_out): the tail of the fused backward kernel when the workgroup owns the head
+  template <int T, int R0, int NR>
+  static FFC_FN void w_acc_read(float sc, A16& re, A16& im) {
+    if constexpr (NR == 1) {
+      re[R0] = B::template agpr_get<32 * T + R0>() * sc;
+      im[R0] = B::template agpr_get<32 * T + 16 + R0>() * sc;
+    } else {
+      w_acc_read<T, R0, NR / 2>(sc, re, im);
+      w_acc_read<T, R0 + NR / 2, NR - NR / 2>(sc, re, im);
+    }
+  }
+  template <int T>
+  static FFC_FN void dk_tail_tile(const DkfArgs& d, Unit un, const InnerRegs& R) {
+    A16 re, im;
+    w_acc_read<T, 0, 16>(d.dk_scale, re, im);
+    BD::template tile_inv<false>(d.c.s_inv, un.wq * GEO::TPW + T, R, un, re, im);
+  }
+  static FFC_FN void dk_tail(const DkfArgs& d, int h, Unit un) {
+    static_assert(GEO::UPW == 1 && WREG == GEO::TPW && GEO::TPW == 4, "dk tail: one unit per workgroup, sums in registers");
+    B::barrier();              // the last pair's output rows have left the exchange buffer
+    InnerRegs R;
+    BD::template load_inner<false>(R, un);
+    dk_tail_tile<0>(d, un, R); dk_tail_tile<1>(d, un, R); dk_tail_tile<2>(d, un, R); dk_tail_tile<3>(d, un, R);
+    B::barrier();
+    BD::template outer_stage<false, false>(d.Lk, un);
+    B::lds_fence();
+    DkArgs ka{};
+    ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
+    dk_rows_out(ka, h, un);
   }
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
@@ -999,6 +1064,9 @@ struct Modes : Body<B, GEO, DT> {
 #endif
 #undef FFC_BTICK
 #undef FFC_BPRIO
+      if constexpr (GEO::UPW == 1 && !RP && DT == DT_BF16 && WREG == GEO::TPW) {
+        if (d.dk_out) { dk_tail(d, h, un); return; }      // dk straight from the accumulation registers (nchunk == 1)
+      }
       w_acc_finish(slab, u, un, W);
     } else if (a.R > 1) {
       // inner-only multi-pass form: pass-major; du / dpregate accumulate over the passes (rows_out_rp)

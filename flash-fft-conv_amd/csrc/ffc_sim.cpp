@@ -350,6 +350,16 @@ static void sim_conv_t(const ConvArgs& a) {
             return;
           }
         }
+        if constexpr (GEO::OUTER && GEO::UPW == 1) {
+          if (a.kfuse_k) {                // k -> k_f of this head inside the same workgroup (conv_kernel, ConvArgs::kfuse_k)
+            Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
+            Modes<SimB, GEO, DT>::kfft_head(a, h);
+            const bool half = (GEO::N1 / 2) * GEO::Mi >= a.L;
+            if (a.zsave) { if (half) Body<SimB, GEO, DT>::template conv_job<true, false, true>(a, h, c); else Body<SimB, GEO, DT>::template conv_job<false, false, true>(a, h, c); }
+            else { if (half) Body<SimB, GEO, DT>::template conv_job<true>(a, h, c); else Body<SimB, GEO, DT>::template conv_job<false>(a, h, c); }
+            return;
+          }
+        }
         if constexpr (GEO::OUTER) {       // the launcher's HALF variant
           if (a.zsave) {                  // spectrum-saving training forward (ffc_conv_fwd_z)
             if ((GEO::N1 / 2) * GEO::Mi >= a.L) Body<SimB, GEO, DT>::template conv<true, true>(a, h, c);
@@ -501,6 +511,12 @@ void ffcsim_set_sparse(int rows) { g_sparse_rows = rows; }      // next ffcsim_c
 static void* g_z = nullptr; static void* g_yraw = nullptr; static int g_flags = 0;
 void ffcsim_set_z(void* z, void* yraw, int flags) { g_z = z; g_yraw = yraw; g_flags = flags; }
 long ffcsim_dma_count() { return g_dma_count.exchange(0); }
+// dk (H, Lk) fp32 written by the NEXT ffcsim_conv_bwd itself (DkfArgs::dk_out, Modes::dk_tail; the caller passes nchunk = 1)
+static float* g_dk_out = nullptr; static int g_dk_lk = 0;
+void ffcsim_set_fused_dk(float* dk, int Lk) { g_dk_out = dk; g_dk_lk = Lk; }
+// k (H, Lk) fp32 transformed by the NEXT ffcsim_conv_fwd itself into its kf argument (ConvArgs::kfuse_k, Modes::kfft_head)
+static const float* g_kfuse_k = nullptr; static int g_kfuse_lk = 0;
+void ffcsim_set_fused_k(const float* k, int Lk) { g_kfuse_k = k; g_kfuse_lk = Lk; }
 static int g_big_pipe = 0;      // as in the library: opt-in
 void ffcsim_set_big_pipe(int on) { g_big_pipe = on; }      // 0: every outer pass through BigBody::run (one block per workgroup)
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
@@ -518,6 +534,9 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.R = p.R;
   a.sparse = g_sparse_rows;
   if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
+  if (g_kfuse_k && N == 32768 && dtype == DT_BF16 && !a.sparse) {
+    a.kfuse_k = g_kfuse_k; a.kfuse_Lk = g_kfuse_lk; a.kfuse_scale = (float)(p.s_k / p.s_fwd); a.kfuse_fast = (g_kfuse_lk % 4 == 0) && !g_force_slow;
+  }
   return dispatch<ConvRun>(N, dtype, a);
 }
 
@@ -650,6 +669,9 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.R = p.R;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
+  if (g_dk_out && a.nchunk == 1 && N == 32768 && dtype == DT_BF16) {
+    d.dk_out = g_dk_out; d.Lk = g_dk_lk; d.dk_scale = (float)(1.0 / p.s_fwd); d.dk_fast = (g_dk_lk % 4 == 0) && !g_force_slow;
+  }
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();
   int rc = dispatch<BwdRun>(N, dtype, d);

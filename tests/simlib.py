@@ -175,8 +175,25 @@ class SimOps:
         return out
 
 
-def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchunk=1):
-    """Fused backward on the simulator: returns (du bits, dpre bits or None, dk fp32)."""
+def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchunk=1, fused_dk=False):
+    """Fused backward on the simulator: returns (du bits, dpre bits or None, dk fp32).  fused_dk: dk written by the backward
+    kernel itself from its accumulation registers (DkfArgs::dk_out; fft 32768 bf16, one chunk) instead of slabs + dkifft."""
+    if fused_dk:
+        B, H, L = u_bits.shape
+        nt, _, _, _ = plan_info(N, dtype)
+        ws = np.full(lib().ffcsim_upw(N) * H * nt * 2048, np.nan, np.float32)
+        du = np.zeros_like(u_bits)
+        dpre = np.zeros_like(u_bits) if pre is not None else None
+        dpost = np.zeros_like(u_bits) if pre is not None else None
+        dk = np.full((H, Lk), np.nan, np.float32)
+        lib().ffcsim_set_fused_dk(p(dk), Lk)
+        try:
+            assert lib().ffcsim_conv_bwd(N, dtype, p(dout_bits), p(u_bits), p(kf_bits), p(pre), p(post), p(du), p(dpre), p(dpost),
+                                         p(ws), B, H, L, 1) > 0
+        finally:
+            lib().ffcsim_set_fused_dk(None, 0)
+        assert np.isnan(ws).all(), "the fused dk tail must not write slabs"
+        return du, dpre, dk
     B, H, L = u_bits.shape
     nt, _, _, _ = plan_info(N, dtype)
     upw = lib().ffcsim_upw(N)

@@ -419,3 +419,45 @@ def test_row_freq_locates_every_bin_of_the_inner_rows(N, fac):
     f = (np.asarray(offs)[:, None] + stride * np.asarray(freq)[None, :]) % N
     got = kf[..., 0] + 1j * kf[..., 1]
     assert rel(got, K[f]) < 2e-2
+
+
+# ---------------------------------------------------------------- dk out of the backward launch itself (Modes::dk_tail): the workgroup that
+# owns every pair of a head inverts its accumulation registers right away -- no fp32 slab, no dkifft launch
+@pytest.mark.parametrize("L,B,H,gated,Lk", [(16384, 4, 2, False, 16384), (16384, 3, 1, True, 16384), (32768, 2, 1, False, 32768),
+                                            (9000, 2, 2, False, 700), (16384, 2, 1, False, 16381)])
+def test_dk_from_the_backward_launch(L, B, H, gated, Lk):
+    N, dt = 32768, 0
+    rng = np.random.default_rng(L + B + Lk)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    du0, dpre0, dk0 = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, Lk, pre, post, 1)
+    du1, dpre1, dk1 = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, Lk, pre, post, 1, fused_dk=True)
+    assert np.array_equal(du0, du1) and (not gated or np.array_equal(dpre0, dpre1))
+    assert not np.isnan(dk1).any() and rel(dk1, dk0.astype(np.float64)) < 1e-3
+    kpad = np.zeros((H, max(L, Lk)), np.float32); kpad[:, :Lk] = k
+    r = O.ref_grads(q(u, dt), kpad[:, :L] if Lk <= L else kpad, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), kpad[:, :L] if Lk <= L else kpad, q(d, dt), N)
+    assert rel(dk1, r[1][:, :Lk]) < 1.5 * TOL[0]
+
+
+# ---------------------------------------------------------------- k -> k_f inside the forward launch (Modes::kfft_head, ConvArgs::kfuse_k)
+@pytest.mark.parametrize("L,B,H,gated,Lk", [(16384, 4, 2, False, 16384), (32768, 2, 1, True, 32768), (9000, 3, 2, False, 700), (16384, 2, 1, False, 16381)])
+def test_kernel_fft_inside_the_forward_launch(L, B, H, gated, Lk):
+    N, dt = 32768, 0
+    rng = np.random.default_rng(L + B + Lk)
+    u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
+    k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    kf0 = S.sim_kernel_fft(N, dt, k)
+    y0 = S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf0, pre, post)
+    kf1 = np.full_like(kf0, 0x7fc0)                   # NaN pattern: the launch has to write every k_f tile it reads
+    kc = np.ascontiguousarray(k)
+    S.lib().ffcsim_set_fused_k(S.p(kc), Lk)
+    try:
+        y1 = S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf1, pre, post)
+    finally:
+        S.lib().ffcsim_set_fused_k(None, 0)
+    assert np.array_equal(kf0, kf1) and np.array_equal(y0, y1)

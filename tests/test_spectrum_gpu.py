@@ -192,3 +192,44 @@ def test_no_spectra_are_stored_without_a_graph():
         assert u.grad is not None and k.grad is not None
     finally:
         C._spectrum_buffer = orig
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gated", [False, True])
+@pytest.mark.parametrize("B,H,L", [(4, 512, 16384), (3, 600, 16376), (2, 512, 32768)])
+def test_one_launch_per_direction_equals_the_separate_kernels(B, H, L, gated):
+    """ffc_conv_fwd_k / ffc_conv_bwd_k at fft 32768 bf16 with a workgroup per head (H >= 512 on 256 CUs): k -> k_f runs inside the
+    forward launch (Modes::kfft_head) and dk comes out of the backward launch (Modes::dk_tail) -- against the same calls with the
+    tuning flags 32 | 64 (k -> k_f and dk_f -> dk as kernels of their own): k_f, y, du, gate gradients bit for bit, dk to rounding."""
+    import os
+    from flashfftconv import FlashFFTConv, conv as C, _lib
+    lib, P, sp = _lib.lib(), _lib.ptr, _lib.stream_ptr
+    N, dt = 32768, torch.bfloat16
+    torch.manual_seed(B + H)
+    u = torch.randn(B, H, L, device="cuda").to(dt); dout = torch.randn(B, H, L, device="cuda").to(dt)
+    k = torch.randn(H, L, device="cuda") * torch.exp(-0.01 * torch.arange(L, device="cuda")) / 4
+    pre = torch.randn_like(u) if gated else None; post = torch.randn_like(u) if gated else None
+    plan = FlashFFTConv(N, dtype=dt).cuda()._get_plan(u.device)
+    res = {}
+    for fl in ("0", "96"):
+        os.environ["FFC_FLAGS"] = fl; C.reload_env()
+        try:
+            kf = torch.full((H, plan.kf_elems, 2), float("nan"), dtype=dt, device="cuda")
+            z = torch.empty(lib.ffc_spectrum_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda")
+            y = torch.full_like(u, 7.0); yraw = torch.full_like(u, 9.0) if gated else None
+            _lib.check(lib.ffc_conv_fwd_k(plan.handle, P(k), L, P(kf), P(u), P(pre), P(post), P(y), P(z), P(yraw), B, H, L, sp()), "fwd_k")
+            ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, B, H), dtype=torch.uint8, device="cuda")
+            du, dpre, dpost = (torch.full_like(u, 3.0) for _ in range(3))
+            dk = torch.full((H, L), float("nan"), device="cuda")
+            g = (lambda t: P(t)) if gated else (lambda t: None)
+            _lib.check(lib.ffc_conv_bwd_k(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(du), g(dpre), g(dpost), P(ws), P(z), P(yraw),
+                                          P(dk), L, B, H, L, sp()), "bwd_k")
+            torch.cuda.synchronize()
+            res[fl] = (kf, y, du, dpre, dpost, dk)
+        finally:
+            os.environ.pop("FFC_FLAGS"); C.reload_env()
+    a, b = res["0"], res["96"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if gated:
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert not torch.isnan(a[5]).any() and rel(a[5], b[5]) < 1e-3, f"dk rel {rel(a[5], b[5]):.2e}"
