@@ -219,11 +219,12 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = ffc_persist(p);
   a.R = p->hp.R;
-  // k -> k_f inside this launch (Modes::kfft_head): a workgroup owns its head, single-pass fft 32768, bf16 plan (fp16 plans
-  // prescale k: kept on the separate kernel); tuning flag 64 keeps the separate launch
-  if (kfuse_k && kfuse_done && a.nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && p->hp.dtype == DT_BF16 && !sparse &&
+  // k -> k_f inside this launch (Modes::kfft_head): a workgroup owns its head, single-pass fft 32768; tuning flag 64 keeps the
+  // separate launch
+  if (kfuse_k && kfuse_done && a.nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && !sparse &&
       !(p->env_flags & 64) && kfuse_Lk > 0 && kfuse_Lk <= p->hp.N && H * kfuse_Lk < ((int64_t)1 << 31)) {
-    a.kfuse_k = kfuse_k; a.kfuse_Lk = (int)kfuse_Lk; a.kfuse_scale = (float)(p->hp.s_k / p->hp.s_fwd);
+    a.kfuse_k = kfuse_k; a.kfuse_Lk = (int)kfuse_Lk;
+    a.kfuse_scale = (float)(p->hp.s_k / p->hp.s_fwd) / (p->hp.dtype == DT_F16 ? 256.f : 1.f);
     a.kfuse_fast = (kfuse_Lk % 4 == 0) && !((uintptr_t)kfuse_k & 15);
     *kfuse_done = true;
   }
@@ -314,7 +315,7 @@ extern "C" int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, voi
   // decide first whether the convolution launch can take the k -> k_f step (same rule as conv_fwd_impl applies below)
   int nchunk = 0, ppc = 0;
   if (B > 0 && H > 0) ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc, true);
-  const bool fuse = nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && p->hp.dtype == DT_BF16 && !(p->env_flags & 64) && Lk > 0 &&
+  const bool fuse = nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && !(p->env_flags & 64) && Lk > 0 &&
                     Lk <= p->hp.N && H * Lk < ((int64_t)1 << 31);
   if (!fuse) {
     int rc = ffc_kernel_fft(p, k, H, Lk, kf_out, stream);

@@ -320,7 +320,8 @@ struct Modes : Body<B, GEO, DT> {
     static_assert(GEO::OUTER && GEO::UPW == 1, "kfft_head: one unit per workgroup");
     KfArgs a{};
     a.k = c.kfuse_k; a.kf = const_cast<void*>(c.kf); a.H = c.H; a.Lk = c.kfuse_Lk; a.scale = c.kfuse_scale; a.s_fwd = c.s_fwd;
-    a.prescale = 1.0f; a.fast = c.kfuse_fast;
+    a.prescale = DT == DT_F16 ? 256.f : 1.f;      // as ffc_kernel_fft: fp16 plans scale k up before rounding it (kfuse_scale carries 1 / 256)
+    a.fast = c.kfuse_fast;
     Unit un;
     un.wq = B::wave() % GEO::NW;
     un.eb = 0;

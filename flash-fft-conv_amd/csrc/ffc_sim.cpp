@@ -534,8 +534,8 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.R = p.R;
   a.sparse = g_sparse_rows;
   if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
-  if (g_kfuse_k && N == 32768 && dtype == DT_BF16 && !a.sparse) {
-    a.kfuse_k = g_kfuse_k; a.kfuse_Lk = g_kfuse_lk; a.kfuse_scale = (float)(p.s_k / p.s_fwd); a.kfuse_fast = (g_kfuse_lk % 4 == 0) && !g_force_slow;
+  if (g_kfuse_k && N == 32768 && !a.sparse) {
+    a.kfuse_k = g_kfuse_k; a.kfuse_Lk = g_kfuse_lk; a.kfuse_scale = (float)(p.s_k / p.s_fwd) / (dtype == DT_F16 ? 256.f : 1.f); a.kfuse_fast = (g_kfuse_lk % 4 == 0) && !g_force_slow;
   }
   return dispatch<ConvRun>(N, dtype, a);
 }

@@ -444,8 +444,9 @@ def test_dk_from_the_backward_launch(L, B, H, gated, Lk):
 
 # ---------------------------------------------------------------- k -> k_f inside the forward launch (Modes::kfft_head, ConvArgs::kfuse_k)
 @pytest.mark.parametrize("L,B,H,gated,Lk", [(16384, 4, 2, False, 16384), (32768, 2, 1, True, 32768), (9000, 3, 2, False, 700), (16384, 2, 1, False, 16381)])
-def test_kernel_fft_inside_the_forward_launch(L, B, H, gated, Lk):
-    N, dt = 32768, 0
+@pytest.mark.parametrize("dt", [0, 1])
+def test_kernel_fft_inside_the_forward_launch(L, B, H, gated, Lk, dt):
+    N = 32768
     rng = np.random.default_rng(L + B + Lk)
     u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
     k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
@@ -453,7 +454,7 @@ def test_kernel_fft_inside_the_forward_launch(L, B, H, gated, Lk):
     post = S.to_bits(g2, dt) if gated else None
     kf0 = S.sim_kernel_fft(N, dt, k)
     y0 = S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf0, pre, post)
-    kf1 = np.full_like(kf0, 0x7fc0)                   # NaN pattern: the launch has to write every k_f tile it reads
+    kf1 = np.full_like(kf0, 0x7fc0 if dt == 0 else 0x7e00)                   # NaN pattern: the launch has to write every k_f tile it reads
     kc = np.ascontiguousarray(k)
     S.lib().ffcsim_set_fused_k(S.p(kc), Lk)
     try:
