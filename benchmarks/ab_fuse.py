@@ -14,8 +14,8 @@ def ev(fn, it=20):
     for _ in range(it): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / it
-flags = sys.argv[1:] or ["0", "32", "64", "96", "104"]
-for (N, B, H, L) in ((32768, 16, 768, 16384), (32768, 16, 768, 32768), (32768, 4, 768, 16384)):
+flags = sys.argv[1:] or ["0", "32", "64", "96"]
+for (N, B, H, L) in ((32768, 16, 768, 16384), (16384, 16, 768, 8192), (8192, 16, 768, 4096), (4096, 16, 768, 2048), (32768, 4, 768, 16384)):
     torch.manual_seed(0)
     u = torch.randn(B, H, L, device="cuda").bfloat16().requires_grad_(True); dout = torch.randn(B, H, L, device="cuda").bfloat16()
     k = (torch.randn(H, L, device="cuda") / 30).requires_grad_(True)

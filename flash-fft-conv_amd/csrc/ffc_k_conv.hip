@@ -37,7 +37,7 @@ __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) vo
     int h, chunk;
     if (!map_block(a.H, a.nchunk, &h, &chunk)) return;
     stagger_start(a.flags);
-    if constexpr (GEO::UPW == 1 && !SP) {
+    if constexpr (GEO::NW > 1 && !SP) {
       // k -> k_f of this head first (ConvArgs::kfuse_k, one chunk per head): no separate launch for it
       BD::setup_tables(a.tab, a.t);
       if (a.kfuse_k) Modes<DevB, GEO, DT>::kfft_head(a, h);
@@ -219,9 +219,9 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   ffc_choose_chunks(p, a.H, a.npair, &a.nchunk, &a.ppc, true);
   a.persist = ffc_persist(p);
   a.R = p->hp.R;
-  // k -> k_f inside this launch (Modes::kfft_head): a workgroup owns its head, single-pass fft 32768; tuning flag 64 keeps the
-  // separate launch
-  if (kfuse_k && kfuse_done && a.nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && !sparse &&
+  // k -> k_f inside this launch (Modes::kfft_head): a workgroup owns its head, fft 8192 / 16384 / 32768 (the sizes whose waves
+  // meet at workgroup barriers anyway); tuning flag 64 keeps the separate launch
+  if (kfuse_k && kfuse_done && a.nchunk == 1 && p->hp.N >= 8192 && p->hp.N <= 32768 && p->hp.R == 1 && !sparse &&
       !(p->env_flags & 64) && kfuse_Lk > 0 && kfuse_Lk <= p->hp.N && H * kfuse_Lk < ((int64_t)1 << 31)) {
     a.kfuse_k = kfuse_k; a.kfuse_Lk = (int)kfuse_Lk;
     a.kfuse_scale = (float)(p->hp.s_k / p->hp.s_fwd) / (p->hp.dtype == DT_F16 ? 256.f : 1.f);
@@ -315,7 +315,7 @@ extern "C" int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, voi
   // decide first whether the convolution launch can take the k -> k_f step (same rule as conv_fwd_impl applies below)
   int nchunk = 0, ppc = 0;
   if (B > 0 && H > 0) ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc, true);
-  const bool fuse = nchunk == 1 && p->hp.N == 32768 && p->hp.R == 1 && !(p->env_flags & 64) && Lk > 0 &&
+  const bool fuse = nchunk == 1 && p->hp.N >= 8192 && p->hp.N <= 32768 && p->hp.R == 1 && !(p->env_flags & 64) && Lk > 0 &&
                     Lk <= p->hp.N && H * Lk < ((int64_t)1 << 31);
   if (!fuse) {
     int rc = ffc_kernel_fft(p, k, H, Lk, kf_out, stream);

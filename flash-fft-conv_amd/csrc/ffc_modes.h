@@ -317,7 +317,10 @@ struct Modes : Body<B, GEO, DT> {
   // head): the single-pass OUTER branch of kfft() for unit `h`.  The plan tables are in LDS already.  Ends with a barrier: the
   // caller's row copies may overwrite the exchange buffer.
   static FFC_FN void kfft_head(const ConvArgs& c, int h) {
-    static_assert(GEO::OUTER && GEO::UPW == 1, "kfft_head: one unit per workgroup");
+    static_assert(GEO::OUTER && GEO::NW > 1, "kfft_head: sizes whose waves meet at workgroup barriers anyway");
+    // (several units per workgroup, fft 8192 / 16384: unit 0's waves transform the filter in their exchange buffer, the others
+    // wait at the two barriers; every wave of the workgroup later reads the tiles from global memory -- __syncthreads orders them)
+    const int unit = B::wave() / GEO::NW;
     KfArgs a{};
     a.k = c.kfuse_k; a.kf = const_cast<void*>(c.kf); a.H = c.H; a.Lk = c.kfuse_Lk; a.scale = c.kfuse_scale; a.s_fwd = c.s_fwd;
     a.prescale = DT == DT_F16 ? 256.f : 1.f;      // as ffc_kernel_fft: fp16 plans scale k up before rounding it (kfuse_scale carries 1 / 256)
@@ -325,18 +328,22 @@ struct Modes : Body<B, GEO, DT> {
     Unit un;
     un.wq = B::wave() % GEO::NW;
     un.eb = 0;
-    k_rows_in(a, h, un);
-    B::lds_fence();
-    if ((GEO::N1 / 2) * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
-    else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
+    if (unit == 0) {
+      k_rows_in(a, h, un);
+      B::lds_fence();
+      if ((GEO::N1 / 2) * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
+      else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
+    }
     B::barrier();
-    InnerRegs R;
-    BD::load_inner(R, un);
+    if (unit == 0) {
+      InnerRegs R;
+      BD::load_inner(R, un);
 #pragma unroll 1
-    for (int tt = 0; tt < GEO::TPW; tt++) {
-      A16 re, im;
-      BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
-      kf_store(a, h, un.wq * GEO::TPW + tt, re, im);
+      for (int tt = 0; tt < GEO::TPW; tt++) {
+        A16 re, im;
+        BD::tile_fwd(un.wq * GEO::TPW + tt, R, un, re, im);
+        kf_store(a, h, un.wq * GEO::TPW + tt, re, im);
+      }
     }
     B::barrier();
   }
@@ -620,6 +627,50 @@ struct Modes : Body<B, GEO, DT> {
     DkArgs ka{};
     ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
     dk_rows_out(ka, h, un);
+  }
+  // Several units per workgroup (fft 4096 / 8192 / 16384: UPW pairs of the same head, each with its own sums): tile by tile every
+  // wave parks its 32 accumulators in the upper half of the (idle) exchange buffers, unit 0's waves add the units up in a fixed
+  // order -- straight into accumulator-shaped registers -- and invert the tile into unit 0's buffer, which lies in the lower half.
+  template <int T>
+  static FFC_FN void dk_tail_tile_multi(const DkfArgs& d, int u, Unit un, const InnerRegs& R, i32 lane) {
+    constexpr int PARK = GEO::L_E + 65536;
+    static_assert(GEO::EBYTES <= 65536 && GEO::UPW * GEO::NW * 8192 == 65536, "parking area = the upper half of the exchange buffers");
+    w_acc_park<T, 0, 32>(PARK + (u * GEO::NW + un.wq) * 8192 + lane * 4);
+    B::barrier();
+    if (u == 0) {
+      A16 re, im;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        f32 sr = B::fconst(0.f), si = B::fconst(0.f);
+#pragma unroll
+        for (int s2 = 0; s2 < GEO::UPW; s2++) {
+          const i32 src = lane * 4 + (PARK + (s2 * GEO::NW + un.wq) * 8192);
+          sr = sr + B::as_f32(B::lds_r32(src + r * 256));
+          si = si + B::as_f32(B::lds_r32(src + (16 + r) * 256));
+        }
+        re[r] = sr * d.dk_scale; im[r] = si * d.dk_scale;
+      }
+      BD::template tile_inv<false>(d.c.s_inv, un.wq * GEO::TPW + T, R, un, re, im);
+    }
+    B::barrier();
+  }
+  static FFC_FN void dk_tail_multi(const DkfArgs& d, int h, int u, Unit un) {
+    static_assert(GEO::UPW > 1 && WREG == GEO::TPW && GEO::TPW == 4, "dk tail: sums in registers");
+    const i32 lane = B::opaque(B::lane());
+    B::barrier();              // every unit's last output rows have left the exchange buffers
+    InnerRegs R;
+    if (u == 0) BD::template load_inner<false>(R, un);
+    dk_tail_tile_multi<0>(d, u, un, R, lane); dk_tail_tile_multi<1>(d, u, un, R, lane);
+    dk_tail_tile_multi<2>(d, u, un, R, lane); dk_tail_tile_multi<3>(d, u, un, R, lane);
+    if (u == 0) {
+      // (one wave per unit, fft 4096: its tiles and its column slice are the whole unit -- program order is enough, as in the pair loop)
+      BD::template outer_stage<false, false>(d.Lk, un);
+      B::lds_fence();
+      DkArgs ka{};
+      ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
+      dk_rows_out(ka, h, un);
+    }
+    B::barrier();              // persistent kernels (fft 4096): the next job's rows may overwrite the buffers
   }
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
@@ -1065,8 +1116,14 @@ struct Modes : Body<B, GEO, DT> {
 #endif
 #undef FFC_BTICK
 #undef FFC_BPRIO
-      if constexpr (GEO::UPW == 1 && !RP && DT == DT_BF16 && WREG == GEO::TPW) {
-        if (d.dk_out) { dk_tail(d, h, un); return; }      // dk straight from the accumulation registers (nchunk == 1)
+      // (not the one-wave-per-unit kernel of fft 4096: with the tail its register allocation overflows into the accumulation
+      // registers, build.py check_agpr)
+      if constexpr (!RP && DT == DT_BF16 && WREG == GEO::TPW && GEO::NW > 1) {
+        if (d.dk_out) {      // dk straight from the accumulation registers (nchunk == 1)
+          if constexpr (GEO::UPW == 1) dk_tail(d, h, un);
+          else dk_tail_multi(d, h, u, un);
+          return;
+        }
       }
       w_acc_finish(slab, u, un, W);
     } else if (a.R > 1) {

@@ -350,7 +350,7 @@ static void sim_conv_t(const ConvArgs& a) {
             return;
           }
         }
-        if constexpr (GEO::OUTER && GEO::UPW == 1) {
+        if constexpr (GEO::OUTER && GEO::NW > 1) {
           if (a.kfuse_k) {                // k -> k_f of this head inside the same workgroup (conv_kernel, ConvArgs::kfuse_k)
             Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
             Modes<SimB, GEO, DT>::kfft_head(a, h);
@@ -534,7 +534,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.R = p.R;
   a.sparse = g_sparse_rows;
   if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
-  if (g_kfuse_k && N == 32768 && !a.sparse) {
+  if (g_kfuse_k && N >= 8192 && N <= 32768 && !a.sparse) {
     a.kfuse_k = g_kfuse_k; a.kfuse_Lk = g_kfuse_lk; a.kfuse_scale = (float)(p.s_k / p.s_fwd) / (dtype == DT_F16 ? 256.f : 1.f); a.kfuse_fast = (g_kfuse_lk % 4 == 0) && !g_force_slow;
   }
   return dispatch<ConvRun>(N, dtype, a);
@@ -669,7 +669,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.R = p.R;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
-  if (g_dk_out && a.nchunk == 1 && N == 32768 && dtype == DT_BF16) {
+  if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768 && dtype == DT_BF16) {
     d.dk_out = g_dk_out; d.Lk = g_dk_lk; d.dk_scale = (float)(1.0 / p.s_fwd); d.dk_fast = (g_dk_lk % 4 == 0) && !g_force_slow;
   }
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);

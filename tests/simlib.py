@@ -177,7 +177,7 @@ class SimOps:
 
 def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchunk=1, fused_dk=False):
     """Fused backward on the simulator: returns (du bits, dpre bits or None, dk fp32).  fused_dk: dk written by the backward
-    kernel itself from its accumulation registers (DkfArgs::dk_out; fft 32768 bf16, one chunk) instead of slabs + dkifft."""
+    kernel itself from its accumulation registers (DkfArgs::dk_out; fft 4096 .. 32768 bf16, one chunk) instead of slabs + dkifft."""
     if fused_dk:
         B, H, L = u_bits.shape
         nt, _, _, _ = plan_info(N, dtype)

@@ -423,10 +423,13 @@ def test_row_freq_locates_every_bin_of_the_inner_rows(N, fac):
 
 # ---------------------------------------------------------------- dk out of the backward launch itself (Modes::dk_tail): the workgroup that
 # owns every pair of a head inverts its accumulation registers right away -- no fp32 slab, no dkifft launch
-@pytest.mark.parametrize("L,B,H,gated,Lk", [(16384, 4, 2, False, 16384), (16384, 3, 1, True, 16384), (32768, 2, 1, False, 32768),
-                                            (9000, 2, 2, False, 700), (16384, 2, 1, False, 16381)])
-def test_dk_from_the_backward_launch(L, B, H, gated, Lk):
-    N, dt = 32768, 0
+@pytest.mark.parametrize("N,L,B,H,gated,Lk", [(32768, 16384, 4, 2, False, 16384), (32768, 16384, 3, 1, True, 16384), (32768, 32768, 2, 1, False, 32768),
+                                              (32768, 9000, 2, 2, False, 700), (32768, 16384, 2, 1, False, 16381),
+                                              # several units per workgroup: the units' sums are added up through LDS first
+                                              (16384, 8192, 5, 2, True, 8192), (16384, 16384, 2, 1, False, 16384), (8192, 4096, 9, 1, False, 4096),
+                                              (8192, 3000, 3, 2, True, 77)])
+def test_dk_from_the_backward_launch(N, L, B, H, gated, Lk):
+    dt = 0
     rng = np.random.default_rng(L + B + Lk)
     u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
     k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
@@ -443,10 +446,11 @@ def test_dk_from_the_backward_launch(L, B, H, gated, Lk):
 
 
 # ---------------------------------------------------------------- k -> k_f inside the forward launch (Modes::kfft_head, ConvArgs::kfuse_k)
-@pytest.mark.parametrize("L,B,H,gated,Lk", [(16384, 4, 2, False, 16384), (32768, 2, 1, True, 32768), (9000, 3, 2, False, 700), (16384, 2, 1, False, 16381)])
+@pytest.mark.parametrize("N,L,B,H,gated,Lk", [(32768, 16384, 4, 2, False, 16384), (32768, 32768, 2, 1, True, 32768), (32768, 9000, 3, 2, False, 700),
+                                              (32768, 16384, 2, 1, False, 16381),
+                                              (16384, 8192, 5, 2, True, 8192), (16384, 16384, 3, 1, False, 101), (8192, 4096, 10, 1, False, 4096), (8192, 8192, 5, 2, True, 8191)])
 @pytest.mark.parametrize("dt", [0, 1])
-def test_kernel_fft_inside_the_forward_launch(L, B, H, gated, Lk, dt):
-    N = 32768
+def test_kernel_fft_inside_the_forward_launch(N, L, B, H, gated, Lk, dt):
     rng = np.random.default_rng(L + B + Lk)
     u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
     k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
