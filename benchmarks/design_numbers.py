@@ -25,11 +25,11 @@ out.append(f"Peak memory of config 2 above the resident inputs ({mb(pm['inputs_b
            f"(forward / fwd+bwd): **{pm['saving_vs_torch_fft_fwd']}× / {pm['saving_vs_torch_fft_fwd_bwd']}× less** than torch.fft (reference README.md:232 publishes 6.65× … 2.81×); "
            f"every row of `configs`, `sweep` and `readme_table` carries the same object.")
 out.append("")
-out.append("| row (module level incl. k → k_f and dk; forward = the TRAINING forward; median of 3 × 20) | fwd / bwd ms | alg. HBM fraction fwd / bwd | round 3 (driver, BENCH_r03) | peak fwd+bwd MB (saved / recompute / torch.fft) |")
+out.append("| row (module level incl. k → k_f and dk; forward = the TRAINING forward; median of 3 × 20) | fwd / bwd ms | alg. HBM fraction fwd / bwd | round 3 (profiles/r03_bench.json) | peak fwd+bwd MB (saved / recompute / torch.fft) |")
 out.append("|---|---|---|---|---|")
 r3 = {}
 try:
-    b3 = json.load(open(os.path.join(ROOT, "BENCH_r03.json")))["parsed"]
+    b3 = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])      # the builder's round-3 run
     for r in b3.get("configs", []) + b3.get("sweep", []):
         r3[r["row"]] = (r.get("fwd_ms"), r.get("bwd_ms"))
 except Exception:
@@ -56,8 +56,12 @@ readme = (f"**{d['ms_per_step']:.2f} ms per fwd+bwd step at B=16, H=768, L=16384
           f"(gated fp16 forward) beaten {min(r['speedup_vs_h100_published'] for r in t):.1f}–{max(r['speedup_vs_h100_published'] for r in t):.1f}× row by row; conv1d k=3 at {d['configs'][3].get('fwd_GBs', 0)/1e3:.1f} TB/s; see `DESIGN.md` §4 and `profiles/`.")
 for path, key, val in ((os.path.join(ROOT, "DESIGN.md"), "@@R4BLOCK@@", block), (os.path.join(ROOT, "README.md"), "@@README_NUMBERS@@", readme)):
     s = open(path).read()
+    a, b = f"<!-- {key.strip('@')} -->", f"<!-- /{key.strip('@')} -->"
     if key in s:
-        open(path, "w").write(s.replace(key, val))
-        print("filled", path)
+        s = s.replace(key, a + "\n" + val + "\n" + b)
+    elif a in s and b in s:
+        s = s[: s.index(a)] + a + "\n" + val + "\n" + s[s.index(b):]
     else:
-        print("no placeholder in", path, "-- printing"); print(val)
+        print("no placeholder in", path); continue
+    open(path, "w").write(s)
+    print("filled", path)
