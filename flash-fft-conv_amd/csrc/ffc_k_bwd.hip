@@ -90,14 +90,14 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
   a.stream = p->env_stream >= 0 ? p->env_stream : ((!pregate && !postgate && p->hp.R == 1) ? 1 : 0);    // see Body::STREAM_ROWS
   a.flags = p->env_flags;                        // tuning flags: 2 = k_f streamed, 4 = scratch streamed
   d.dout = dout; d.ws = (float*)ws; d.du = du; d.dpre = dpre; d.zscratch = ffc_zscratch(p, ws, a.H, a.nchunk);
-  // dk from the same launch (Modes::dk_tail / dk_tail_multi): the workgroup owns all pairs of its head, fft 16384 / 32768 (8192 on request), bf16 plan
+  // dk from the same launch (Modes::dk_tail / dk_tail_multi): the workgroup owns all pairs of its head, fft 16384 / 32768 (8192 on request)
   // (tuning flag 32 keeps the slab + ffc_kernel_ifft_grad pair)
   // (fft 8192: the tail runs on 2 of the workgroup's 8 waves and measured +-0 / +2 % on the backward call, profiles/
   // r04_ab_launch_fusion.txt: kept on the separate kernel unless tuning flag 128 asks for it)
   if (dk && dk_done && a.nchunk == 1 && p->hp.N >= ((p->env_flags & 128) ? 8192 : 16384) && p->hp.N <= 32768 && p->hp.R == 1 &&
-      p->hp.dtype == DT_BF16 && !(p->env_flags & 32) &&
-      Lk > 0 && Lk <= p->hp.N) {
+      !(p->env_flags & 32) && Lk > 0 && Lk <= p->hp.N) {
     d.dk_out = dk; d.Lk = (int)Lk; d.dk_scale = (float)(1.0 / p->hp.s_fwd);
+    d.tab_bf = p->d_blob_bf; d.t_bf = p->hp_bf.tabs;      // (fp16 plans: bf16 tables for the tail)
     d.dk_fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
     *dk_done = true;
   }

@@ -57,6 +57,10 @@ struct DkfArgs {
   float* dk_out;
   int Lk, dk_fast;
   float dk_scale;      // 1 / s_fwd (W carries s_fwd^2, tile_inv applies 1 / (N s_fwd))
+  // fp16 plans: the plan's bf16 tables (the dk inverse runs in bf16 operand arithmetic for fp32's range, as ffc_kernel_ifft_grad
+  // does).  The fp16 kernel swaps them into LDS behind its pair loop and runs the bf16 instantiation of the tail.
+  const uint8_t* tab_bf;
+  PlanTabs t_bf;
 };
 
 struct DkArgs {
@@ -609,14 +613,16 @@ struct Modes : Body<B, GEO, DT> {
       w_acc_read<T, R0 + NR / 2, NR - NR / 2>(sc, re, im);
     }
   }
+  static FFC_FN Unit unit_of(int u, int wq) { Unit un; un.wq = wq; un.eb = u * GEO::EBYTES; return un; }
   template <int T>
   static FFC_FN void dk_tail_tile(const DkfArgs& d, Unit un, const InnerRegs& R) {
     A16 re, im;
     w_acc_read<T, 0, 16>(d.dk_scale, re, im);
     BD::template tile_inv<false>(d.c.s_inv, un.wq * GEO::TPW + T, R, un, re, im);
   }
-  static FFC_FN void dk_tail(const DkfArgs& d, int h, Unit un) {
+  static FFC_FN void dk_tail(const DkfArgs& d, int h, int wq) {
     static_assert(GEO::UPW == 1 && WREG == GEO::TPW && GEO::TPW == 4, "dk tail: one unit per workgroup, sums in registers");
+    const Unit un = unit_of(0, wq);
     B::barrier();              // the last pair's output rows have left the exchange buffer
     InnerRegs R;
     BD::template load_inner<false>(R, un);
@@ -654,8 +660,9 @@ struct Modes : Body<B, GEO, DT> {
     }
     B::barrier();
   }
-  static FFC_FN void dk_tail_multi(const DkfArgs& d, int h, int u, Unit un) {
+  static FFC_FN void dk_tail_multi(const DkfArgs& d, int h, int u, int wq) {
     static_assert(GEO::UPW > 1 && WREG == GEO::TPW && GEO::TPW == 4, "dk tail: sums in registers");
+    const Unit un = unit_of(u, wq);
     const i32 lane = B::opaque(B::lane());
     B::barrier();              // every unit's last output rows have left the exchange buffers
     InnerRegs R;
@@ -1118,10 +1125,15 @@ struct Modes : Body<B, GEO, DT> {
 #undef FFC_BPRIO
       // (not the one-wave-per-unit kernel of fft 4096: with the tail its register allocation overflows into the accumulation
       // registers, build.py check_agpr)
-      if constexpr (!RP && DT == DT_BF16 && WREG == GEO::TPW && GEO::NW > 1) {
+      if constexpr (!RP && WREG == GEO::TPW && GEO::NW > 1) {
         if (d.dk_out) {      // dk straight from the accumulation registers (nchunk == 1)
-          if constexpr (GEO::UPW == 1) dk_tail(d, h, un);
-          else dk_tail_multi(d, h, u, un);
+          using MB = Modes<B, GEO, DT_BF16>;       // the dk inverse always runs in bf16 operand arithmetic
+          if constexpr (DT != DT_BF16) {           // fp16 plan: swap the plan's bf16 tables into LDS first
+            B::barrier();
+            MB::BD::setup_tables(d.tab_bf, d.t_bf);
+          }
+          if constexpr (GEO::UPW == 1) MB::dk_tail(d, h, un.wq);
+          else MB::dk_tail_multi(d, h, u, un.wq);
           return;
         }
       }

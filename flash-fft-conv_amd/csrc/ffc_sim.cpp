@@ -669,8 +669,11 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.R = p.R;
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
-  if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768 && dtype == DT_BF16) {
+  HostPlan pbf;
+  if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768) {
     d.dk_out = g_dk_out; d.Lk = g_dk_lk; d.dk_scale = (float)(1.0 / p.s_fwd); d.dk_fast = (g_dk_lk % 4 == 0) && !g_force_slow;
+    if (!build_plan(N, DT_BF16, &pbf)) return -1;
+    d.tab_bf = pbf.blob.data(); d.t_bf = pbf.tabs;
   }
   std::vector<uint8_t> zs((size_t)H * a.nchunk * upw * N * 4 + 16);
   d.zscratch = zs.data();

@@ -428,8 +428,8 @@ def test_row_freq_locates_every_bin_of_the_inner_rows(N, fac):
                                               # several units per workgroup: the units' sums are added up through LDS first
                                               (16384, 8192, 5, 2, True, 8192), (16384, 16384, 2, 1, False, 16384), (8192, 4096, 9, 1, False, 4096),
                                               (8192, 3000, 3, 2, True, 77)])
-def test_dk_from_the_backward_launch(N, L, B, H, gated, Lk):
-    dt = 0
+@pytest.mark.parametrize("dt", [0, 1])
+def test_dk_from_the_backward_launch(N, L, B, H, gated, Lk, dt):
     rng = np.random.default_rng(L + B + Lk)
     u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
     k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
