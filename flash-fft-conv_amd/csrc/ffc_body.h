@@ -78,6 +78,7 @@ struct ConvArgs {
   // transforms ITS head's filter into `kf` (Modes::kfft_head: the k -> k_f kernel's work for one head, then phase B reads the tiles
   // the same wave stored), so the forward needs no separate k -> k_f launch.  kf stays an output: the backward pass reads it.
   const float* kfuse_k;
+  const void* kfuse_x;     // instead of kfuse_k: complex input, pair-plane tensor (2, H, N) dtype (inner k_f rows of the HBM-level sizes)
   int kfuse_Lk, kfuse_fast;
   float kfuse_scale;       // s_k / s_fwd (KfArgs::scale; bf16 plans: prescale 1)
 };

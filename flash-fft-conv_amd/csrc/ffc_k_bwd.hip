@@ -61,7 +61,7 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
                          const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, int64_t B, int64_t H,
                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                          int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream, const void* yraw = nullptr,
-                         float* dk = nullptr, int64_t Lk = 0, bool* dk_done = nullptr) {
+                         float* dk = nullptr, int64_t Lk = 0, bool* dk_done = nullptr, void* dk_pair = nullptr, float dk_pair_scale = 1.0f) {
   if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
   if (yraw && (!zin || !dpost)) return ffc_fail("y_raw needs the saved spectra and a dpost output");
   if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
@@ -99,6 +99,13 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
     d.dk_out = dk; d.Lk = (int)Lk; d.dk_scale = (float)(1.0 / p->hp.s_fwd);
     d.tab_bf = p->d_blob_bf; d.t_bf = p->hp_bf.tabs;      // (fp16 plans: bf16 tables for the tail)
     d.dk_fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+    *dk_done = true;
+  }
+  // ... as complex rows (ffc_conv_bwd_kx: first step of dk at the HBM-level sizes; always bf16, the caller's scale)
+  if (dk_pair && dk_done && a.nchunk == 1 && p->hp.N >= ((p->env_flags & 128) ? 8192 : 16384) && p->hp.N <= 32768 && p->hp.R == 1 &&
+      !(p->env_flags & 32) && !((uintptr_t)dk_pair & 15)) {
+    d.dk_pair = dk_pair; d.Lk = p->hp.N; d.dk_scale = dk_pair_scale; d.dk_fast = 1;
+    d.tab_bf = p->d_blob_bf; d.t_bf = p->hp_bf.tabs;
     *dk_done = true;
   }
   d.dpost = (p->hp.N1 > 1 || yraw) ? dpost : nullptr;      // with y_raw every geometry writes dpost from its dout row load
@@ -176,4 +183,18 @@ extern "C" int ffc_conv_bwd_k(const ffc_plan* p, const void* dout, const void* u
                          &dk_done);
   if (rc || dk_done) return rc;
   return ffc_kernel_ifft_grad(p, ws, B, H, Lk, dk, stream);
+}
+
+// The backward of an HBM-level size's inner convolution in one call: input-gradient rows du and the dk rows as a complex pair-plane
+// tensor (2, H, N) bf16 (as ffc_kernel_ifft_grad_c with `scale`), out of the backward launch itself where a workgroup owns its
+// "head", through the fp32 slabs in ws otherwise.  zin: the spectra ffc_conv_fwd_kx kept (nullable).
+extern "C" int ffc_kernel_ifft_grad_c(const ffc_plan* p, const void* ws, int64_t B, int64_t H, void* outpair, float scale, void* stream);
+extern "C" int ffc_conv_bwd_kx(const ffc_plan* p, const void* dout, const void* u, const void* kf, void* du, void* ws, const void* zin,
+                               void* outpair, float scale, int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!outpair) return ffc_fail("null outpair");
+  bool dk_done = false;
+  int rc = conv_bwd_impl(p, dout, u, kf, nullptr, nullptr, du, nullptr, nullptr, ws, zin, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream, nullptr,
+                         nullptr, 0, &dk_done, outpair, scale);
+  if (rc || dk_done) return rc;
+  return ffc_kernel_ifft_grad_c(p, ws, B, H, outpair, scale, stream);
 }

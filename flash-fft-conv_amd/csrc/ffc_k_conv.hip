@@ -40,7 +40,7 @@ __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) vo
     if constexpr (GEO::NW > 1 && !SP) {
       // k -> k_f of this head first (ConvArgs::kfuse_k, one chunk per head): no separate launch for it
       BD::setup_tables(a.tab, a.t);
-      if (a.kfuse_k) Modes<DevB, GEO, DT>::kfft_head(a, h);
+      if (a.kfuse_k || a.kfuse_x) Modes<DevB, GEO, DT>::kfft_head(a, h);
       BD::template conv_job<HALF, false, SZ, SP>(a, h, chunk);
     } else {
       BD::template conv<HALF, SZ, SP>(a, h, chunk);
@@ -193,7 +193,7 @@ extern "C" int64_t ffc_spectrum_bytes(const ffc_plan* p, int64_t B, int64_t H) {
 static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate,
                          void* y, void* zsave, void* yraw, int sparse, int64_t B, int64_t H, int64_t L, int conj_kf, int64_t sb_u, int64_t sb_pre,
                          int64_t sb_post, int64_t sb_y, void* stream, const float* kfuse_k = nullptr, int64_t kfuse_Lk = 0,
-                         bool* kfuse_done = nullptr) {
+                         bool* kfuse_done = nullptr, const void* kfuse_x = nullptr, float kfuse_xscale = 1.0f) {
   if (!p || !u || !kf || !y) return ffc_fail("null arg");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -226,6 +226,12 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
     a.kfuse_k = kfuse_k; a.kfuse_Lk = (int)kfuse_Lk;
     a.kfuse_scale = (float)(p->hp.s_k / p->hp.s_fwd) / (p->hp.dtype == DT_F16 ? 256.f : 1.f);
     a.kfuse_fast = (kfuse_Lk % 4 == 0) && !((uintptr_t)kfuse_k & 15);
+    *kfuse_done = true;
+  }
+  // ... from complex rows (ffc_conv_fwd_kx: the inner k_f rows of the HBM-level sizes, the caller's scale)
+  if (kfuse_x && kfuse_done && a.nchunk == 1 && p->hp.N >= 8192 && p->hp.N <= 32768 && p->hp.R == 1 && !sparse &&
+      !(p->env_flags & 64) && !((uintptr_t)kfuse_x & 15)) {
+    a.kfuse_x = kfuse_x; a.kfuse_scale = kfuse_xscale; a.kfuse_Lk = p->hp.N; a.kfuse_fast = 1;
     *kfuse_done = true;
   }
   // every row is read / written exactly once per launch (multi-pass sizes re-read the rows in every pass: plain accesses)
@@ -324,6 +330,28 @@ extern "C" int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, voi
   bool done = false;
   int rc = conv_fwd_impl(p, u, kf_out, pregate, postgate, y, zsave, zsave ? y_raw : nullptr, 0, B, H, L, 0, 0, 0, 0, 0, stream,
                          fuse ? k : nullptr, Lk, &done);
+  if (rc) return rc;
+  if (fuse && !done) return ffc_fail("internal: the convolution launch did not take the k -> k_f step");
+  return 0;
+}
+
+// The forward of an HBM-level size's inner convolution in one call: the inner k_f rows from their complex input (pair-plane tensor
+// (2, H, N), as ffc_kernel_fft_c; `scale` = that call's scale) into kf_out, then the convolution of the rows `u` (no gates at this
+// level), spectra kept in zsave when given.  k -> k_f runs inside the convolution launch where a workgroup owns its "head".
+extern "C" int ffc_kernel_fft_c(const ffc_plan* p, const void* xpair, int64_t H, void* kf, float scale, void* stream);
+extern "C" int ffc_conv_fwd_kx(const ffc_plan* p, const void* xpair, float scale, void* kf_out, const void* u, void* y, void* zsave,
+                               int64_t B, int64_t H, int64_t L, void* stream) {
+  if (!p || !xpair || !kf_out) return ffc_fail("null arg");
+  int nchunk = 0, ppc = 0;
+  if (B > 0 && H > 0) ffc_choose_chunks(p, (int)H, (int)((B + 1) / 2), &nchunk, &ppc, true);
+  const bool fuse = nchunk == 1 && p->hp.N >= 8192 && p->hp.N <= 32768 && p->hp.R == 1 && !(p->env_flags & 64) && !((uintptr_t)xpair & 15);
+  if (!fuse) {
+    int rc = ffc_kernel_fft_c(p, xpair, H, kf_out, scale, stream);
+    if (rc) return rc;
+  }
+  bool done = false;
+  int rc = conv_fwd_impl(p, u, kf_out, nullptr, nullptr, y, zsave, nullptr, 0, B, H, L, 0, 0, 0, 0, 0, stream, nullptr, 0, &done,
+                         fuse ? xpair : nullptr, scale);
   if (rc) return rc;
   if (fuse && !done) return ffc_fail("internal: the convolution launch did not take the k -> k_f step");
   return 0;

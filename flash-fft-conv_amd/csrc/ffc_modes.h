@@ -61,6 +61,9 @@ struct DkfArgs {
   // does).  The fp16 kernel swaps them into LDS behind its pair loop and runs the bf16 instantiation of the tail.
   const uint8_t* tab_bf;
   PlanTabs t_bf;
+  // instead of dk_out: complex output of the tail, pair-plane tensor (2, H, N) bf16 (first step of dk at the HBM-level sizes, as
+  // ffc_kernel_ifft_grad_c); dk_scale is then the caller's scale
+  void* dk_pair;
 };
 
 struct DkArgs {
@@ -333,7 +336,14 @@ struct Modes : Body<B, GEO, DT> {
     un.wq = B::wave() % GEO::NW;
     un.eb = 0;
     if (unit == 0) {
-      k_rows_in(a, h, un);
+      if (c.kfuse_x) {         // complex rows (pair-plane tensor): the k -> k_f step of the HBM-level sizes (kfft()'s xpair branch)
+        ConvArgs cv{};
+        cv.u = c.kfuse_x; cv.B = 2; cv.H = c.H; cv.L = GEO::N; cv.fast = 1; cv.sbu = (int64_t)c.H * GEO::N;
+        BD::rows_in(cv, h, 0, un);
+        a.Lk = GEO::N; a.prescale = 1.0f;
+      } else {
+        k_rows_in(a, h, un);
+      }
       B::lds_fence();
       if ((GEO::N1 / 2) * GEO::Mi >= a.Lk) BD::template outer_stage<true, true>(a.Lk, un, a.s_fwd);
       else BD::template outer_stage<true, false>(a.Lk, un, a.s_fwd);
@@ -614,6 +624,18 @@ struct Modes : Body<B, GEO, DT> {
     }
   }
   static FFC_FN Unit unit_of(int u, int wq) { Unit un; un.wq = wq; un.eb = u * GEO::EBYTES; return un; }
+  // rows of the inverted dk_f: real part -> dk (H, Lk) fp32, or both planes -> the pair-plane tensor (DkfArgs::dk_pair)
+  static FFC_FN void dk_tail_rows(const DkfArgs& d, int h, Unit un) {
+    if (d.dk_pair) {
+      ConvArgs cv{};
+      cv.y = d.dk_pair; cv.B = 2; cv.H = d.c.H; cv.L = GEO::N; cv.fast = 1; cv.sby = (int64_t)d.c.H * GEO::N;
+      BD::rows_out(cv, h, 0, un);
+    } else {
+      DkArgs ka{};
+      ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
+      dk_rows_out(ka, h, un);
+    }
+  }
   template <int T>
   static FFC_FN void dk_tail_tile(const DkfArgs& d, Unit un, const InnerRegs& R) {
     A16 re, im;
@@ -630,9 +652,7 @@ struct Modes : Body<B, GEO, DT> {
     B::barrier();
     BD::template outer_stage<false, false>(d.Lk, un);
     B::lds_fence();
-    DkArgs ka{};
-    ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
-    dk_rows_out(ka, h, un);
+    dk_tail_rows(d, h, un);
   }
   // Several units per workgroup (fft 4096 / 8192 / 16384: UPW pairs of the same head, each with its own sums): tile by tile every
   // wave parks its 32 accumulators in the upper half of the (idle) exchange buffers, unit 0's waves add the units up in a fixed
@@ -673,9 +693,7 @@ struct Modes : Body<B, GEO, DT> {
       // (one wave per unit, fft 4096: its tiles and its column slice are the whole unit -- program order is enough, as in the pair loop)
       BD::template outer_stage<false, false>(d.Lk, un);
       B::lds_fence();
-      DkArgs ka{};
-      ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast;
-      dk_rows_out(ka, h, un);
+      dk_tail_rows(d, h, un);
     }
     B::barrier();              // persistent kernels (fft 4096): the next job's rows may overwrite the buffers
   }
@@ -1126,7 +1144,7 @@ struct Modes : Body<B, GEO, DT> {
       // (not the one-wave-per-unit kernel of fft 4096: with the tail its register allocation overflows into the accumulation
       // registers, build.py check_agpr)
       if constexpr (!RP && WREG == GEO::TPW && GEO::NW > 1) {
-        if (d.dk_out) {      // dk straight from the accumulation registers (nchunk == 1)
+        if (d.dk_out || d.dk_pair) {      // dk straight from the accumulation registers (nchunk == 1)
           using MB = Modes<B, GEO, DT_BF16>;       // the dk inverse always runs in bf16 operand arithmetic
           if constexpr (DT != DT_BF16) {           // fp16 plan: swap the plan's bf16 tables into LDS first
             B::barrier();

@@ -351,7 +351,7 @@ static void sim_conv_t(const ConvArgs& a) {
           }
         }
         if constexpr (GEO::OUTER && GEO::NW > 1) {
-          if (a.kfuse_k) {                // k -> k_f of this head inside the same workgroup (conv_kernel, ConvArgs::kfuse_k)
+          if (a.kfuse_k || a.kfuse_x) {   // k -> k_f of this head inside the same workgroup (conv_kernel, ConvArgs::kfuse_k / kfuse_x)
             Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
             Modes<SimB, GEO, DT>::kfft_head(a, h);
             const bool half = (GEO::N1 / 2) * GEO::Mi >= a.L;
@@ -517,6 +517,11 @@ void ffcsim_set_fused_dk(float* dk, int Lk) { g_dk_out = dk; g_dk_lk = Lk; }
 // k (H, Lk) fp32 transformed by the NEXT ffcsim_conv_fwd itself into its kf argument (ConvArgs::kfuse_k, Modes::kfft_head)
 static const float* g_kfuse_k = nullptr; static int g_kfuse_lk = 0;
 void ffcsim_set_fused_k(const float* k, int Lk) { g_kfuse_k = k; g_kfuse_lk = Lk; }
+// complex forms (HBM-level sizes): k_f rows from a pair-plane tensor (ConvArgs::kfuse_x), dk rows into one (DkfArgs::dk_pair)
+static const void* g_kfuse_x = nullptr; static float g_kfuse_xscale = 1.f;
+void ffcsim_set_fused_kx(const void* xpair, float scale) { g_kfuse_x = xpair; g_kfuse_xscale = scale; }
+static void* g_dk_pair = nullptr; static float g_dk_pair_scale = 1.f;
+void ffcsim_set_fused_dkpair(void* outpair, float scale) { g_dk_pair = outpair; g_dk_pair_scale = scale; }
 static int g_big_pipe = 0;      // as in the library: opt-in
 void ffcsim_set_big_pipe(int on) { g_big_pipe = on; }      // 0: every outer pass through BigBody::run (one block per workgroup)
 int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void* pregate, const void* postgate,
@@ -534,6 +539,9 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.R = p.R;
   a.sparse = g_sparse_rows;
   if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
+  if (g_kfuse_x && N >= 8192 && N <= 32768 && !a.sparse) {
+    a.kfuse_x = g_kfuse_x; a.kfuse_scale = g_kfuse_xscale; a.kfuse_Lk = N; a.kfuse_fast = 1;
+  }
   if (g_kfuse_k && N >= 8192 && N <= 32768 && !a.sparse) {
     a.kfuse_k = g_kfuse_k; a.kfuse_Lk = g_kfuse_lk; a.kfuse_scale = (float)(p.s_k / p.s_fwd) / (dtype == DT_F16 ? 256.f : 1.f); a.kfuse_fast = (g_kfuse_lk % 4 == 0) && !g_force_slow;
   }
@@ -670,7 +678,11 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
   if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
   HostPlan pbf;
-  if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768) {
+  if (g_dk_pair && a.nchunk == 1 && N >= 8192 && N <= 32768) {
+    d.dk_pair = g_dk_pair; d.Lk = N; d.dk_scale = g_dk_pair_scale; d.dk_fast = 1;
+    if (!build_plan(N, DT_BF16, &pbf)) return -1;
+    d.tab_bf = pbf.blob.data(); d.t_bf = pbf.tabs;
+  } else if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768) {
     d.dk_out = g_dk_out; d.Lk = g_dk_lk; d.dk_scale = (float)(1.0 / p.s_fwd); d.dk_fast = (g_dk_lk % 4 == 0) && !g_force_slow;
     if (!build_plan(N, DT_BF16, &pbf)) return -1;
     d.tab_bf = pbf.blob.data(); d.t_bf = pbf.tabs;

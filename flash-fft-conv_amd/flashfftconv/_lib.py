@@ -38,6 +38,8 @@ def lib():
         L.ffc_conv_bwd_zy.argtypes = [c_vp] * 12 + [c_i64] * 10 + [c_vp]
         L.ffc_conv_fwd_k.argtypes = [c_vp, c_vp, c_i64] + [c_vp] * 7 + [c_i64] * 3 + [c_vp]
         L.ffc_conv_bwd_k.argtypes = [c_vp] * 13 + [c_i64] * 4 + [c_vp]
+        L.ffc_conv_fwd_kx.argtypes = [c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]
+        L.ffc_conv_bwd_kx.argtypes = [c_vp] * 8 + [ctypes.c_float, c_i64, c_i64, c_i64, c_vp]
         L.ffc_dkf_workspace_bytes.argtypes = [c_vp, c_i64, c_i64]; L.ffc_dkf_workspace_bytes.restype = c_i64
         L.ffc_dkf_slab_count.argtypes = [c_vp, c_i64, c_i64]; L.ffc_dkf_slab_count.restype = c_i64
         L.ffc_conv_bwd_dkf.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp]

@@ -134,6 +134,29 @@ def kernel_fft(ops, dt, N, k, H, Lk, fac=None):
     return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre))
 
 
+def kernel_rows(ops, dt, N, k, H, Lk, fac=None):
+    """k (H, Lk) fp32 -> (x, scale): the complex inner rows (2, H*prod(N0), M) whose M-point transform, times `scale`, is the
+    unscaled k_f of kernel_fft -- for callers that run that last transform inside their convolution launch (ffc_conv_fwd_kx)"""
+    factors, M = fac or BIG_FACTORS[N]
+    pre = ops.k_prescale(dt)
+    kx = ops.to_dtype_rows(dt, k, H, Lk, pre)
+    return levels_forward(ops, dt, N, kx, 1, H, Lk, None, fac), 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre)
+
+
+def dk_pair_scale(N, fac=None):
+    """scale of the inner dk_f -> complex rows step (ffc_kernel_ifft_grad_c / the backward launch's tail)"""
+    factors, M = fac or BIG_FACTORS[N]
+    return 1.0 / (inner_sfwd(M) * prod_scale(N, fac))
+
+
+def dk_from_pair(ops, N, y, H, Lk, fac=None):
+    """complex rows of the inverted inner dk_f, (2, H*prod(N0), M) bf16 -> dk (H, Lk) fp32: the levels of dk_from_slabs"""
+    BF = ops.BF16
+    out = ops.empty_pair(BF, 1, H, Lk)
+    levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac)
+    return ops.to_float_rows(out, H, Lk)
+
+
 def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None, fac=None):
     """fp32 W slabs of the inner size -> dk (H, Lk) fp32.  Always bf16 arithmetic (fp32 range).
     nslab: `ws` holds that many caller-owned slabs (hp, kf_elems, 2) instead of a backward launch's workspace."""

@@ -230,6 +230,7 @@ def _kernel_fft(plan, k):
     return kf
 
 
+_BIG_ONE_CALL = _os.environ.get("FFC_BIG_ONE_CALL", "1") != "0"      # A/B switch: "0" = kfft_c / conv / bwd / dkifft_c as separate calls
 _ONE_LAUNCH_LEVEL = _os.environ.get("FFC_BIG_ONE_LAUNCH", "1") != "0"      # A/B switch: "0" = one launch per pass (ffc_outer_pass_r)
 
 
@@ -297,6 +298,30 @@ class _TorchOps:
         _lib.check(lib.ffc_conv_bwd_dkf(plan.handle, _lib.ptr(xd), _lib.ptr(xu), None, None, _lib.ptr(ws), Bp, hp, M,
                                         _lib.stream_ptr()), "ffc_conv_bwd_dkf")
         return ws
+
+    def conv_kx(self, dt, M, x, xk, scale, keep):
+        """inner forward in ONE call (ffc_conv_fwd_kx): k_f rows from their complex input xk (inside the convolution launch where a
+        workgroup owns its row), the convolution of x, spectra kept when `keep` -> (y, k_f, z or None)"""
+        plan = self._plan(M)
+        Bp, hp, _ = x.shape
+        kf = torch.empty(hp, plan.kf_elems, 2, dtype=dt, device=self.device)
+        z = _spectrum_buffer(plan, Bp, hp, self.device, True, self.mod.save_spectrum) if keep else None
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().ffc_conv_fwd_kx(plan.handle, _lib.ptr(xk), ctypes.c_float(scale), _lib.ptr(kf), _lib.ptr(x), _lib.ptr(y),
+                                              _lib.ptr(z), Bp, hp, M, _lib.stream_ptr()), "ffc_conv_fwd_kx")
+        return y, kf, z
+
+    def bwd_dk(self, dt, M, xd, xu, kf, z, scale):
+        """inner backward in ONE call (ffc_conv_bwd_kx): input-gradient rows + the dk rows as a complex pair-plane tensor (bf16)"""
+        plan = self._plan(M)
+        Bp, hp, _ = xu.shape
+        lib = _lib.lib()
+        ws = torch.empty(_ws_bytes(plan, Bp, hp), dtype=torch.uint8, device=self.device)
+        yd = torch.empty_like(xd)
+        out = torch.empty(2, hp, M, dtype=torch.bfloat16, device=self.device)
+        _lib.check(lib.ffc_conv_bwd_kx(plan.handle, _lib.ptr(xd), _lib.ptr(xu), _lib.ptr(kf), _lib.ptr(yd), _lib.ptr(ws), _lib.ptr(z),
+                                       _lib.ptr(out), ctypes.c_float(scale), Bp, hp, M, _lib.stream_ptr()), "ffc_conv_bwd_kx")
+        return yd, out
 
     def conv_save(self, dt, M, x, kf):
         """inner forward that also keeps the inner spectra (None when the inner plan has no such path)"""
@@ -366,17 +391,24 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
     ops = _TorchOps(mod, u.device)
     B, H, L = u.shape
     M = (fac or _big.BIG_FACTORS[N])[1]
-    if kf is None:
-        kf = _big_kernel_fft(mod, k, fac)
-        if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py): zero the inner rows' bins |f| >= keep
-            m = _big_kf_mask(mod, fac, u.device, kf.dtype)
-            kf.view(H, m.shape[0], m.shape[1], 2).mul_(m[None, :, :, None])
-    x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
     z = None
-    if keep:
-        y, z = ops.conv_save(dt, M, x, kf)
+    if kf is None and mod._kf_keep is None and _BIG_ONE_CALL:
+        # one call for the inner k_f rows + the inner convolution (round 4: the last k -> k_f transform runs inside the convolution
+        # launch where a workgroup owns its row, ffc_conv_fwd_kx)
+        xk, sc = _big.kernel_rows(ops, dt, N, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1], fac)
+        x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
+        y, kf, z = ops.conv_kx(dt, M, x, xk, sc, keep)
     else:
-        y = ops.conv(dt, M, x, kf, False)
+        if kf is None:
+            kf = _big_kernel_fft(mod, k, fac)
+            if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py): zero the inner rows' bins |f| >= keep
+                m = _big_kf_mask(mod, fac, u.device, kf.dtype)
+                kf.view(H, m.shape[0], m.shape[1], 2).mul_(m[None, :, :, None])
+        x = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
+        if keep:
+            y, z = ops.conv_save(dt, M, x, kf)
+        else:
+            y = ops.conv(dt, M, x, kf, False)
     out = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate, None, fac)
     return out, kf, ((x, z, y if pregate is not None else None) if keep else None)
@@ -403,6 +435,11 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
     xu, z, yu = kept if kept is not None else (_big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac), None, None)
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
+    if not want_dkf and mod._kf_keep is None and _BIG_ONE_CALL:
+        # one call: the fused inner backward + the inner dk_f -> complex rows step (out of the same launch where a workgroup owns its row)
+        yd, ypair = ops.bwd_dk(dt, M, xd, xu, kf, z, _big.dk_pair_scale(N, fac))
+        dk = _big.dk_from_pair(ops, N, ypair, H, k_len, fac)
+        return _big_backward_tail(mod, ops, dt, N, yd, dk, u, dout, xu, yu, kf, pregate, B, H, L, M, fac)
     yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
     if mod._kf_keep is not None:
         # d/dk of (mask * FFT(k)): mask the fp32 inner dk_f partial sums (same row / position order as k_f) before the inverse
@@ -419,6 +456,11 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
         dk = slabs[0] if nslab == 1 else slabs.sum(0)
     else:
         dk = _big.dk_from_slabs(ops, N, ws, xu.shape[0], H, k_len, None, fac)
+    return _big_backward_tail(mod, ops, dt, N, yd, dk, u, dout, xu, yu, kf, pregate, B, H, L, M, fac)
+
+
+def _big_backward_tail(mod, ops, dt, N, yd, dk, u, dout, xu, yu, kf, pregate, B, H, L, M, fac):
+    """the inverse levels of the gradients: du (* pregate), and for the gated form dpregate, dpostgate"""
     du = torch.empty_like(u)
     shared = {}
     _big.levels_inverse(ops, dt, N, yd, du, B, H, L, pregate, shared, fac)

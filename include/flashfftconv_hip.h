@@ -124,6 +124,14 @@ int ffc_conv_fwd_k(const ffc_plan* plan, const float* k, int64_t Lk, void* kf_ou
 int ffc_conv_bwd_k(const ffc_plan* plan, const void* dout, const void* u, const void* kf, const void* pregate, const void* postgate,
                    void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw, float* dk, int64_t Lk, int64_t B,
                    int64_t H, int64_t L, void* stream);
+/* The same pair for the INNER convolution of the HBM-level sizes (fft >= 262144; flashfftconv/bigfft.py): ffc_conv_fwd_kx =
+ * ffc_kernel_fft_c (complex rows -> kf_out, `scale`) + the ungated forward (spectra kept in zsave when given); ffc_conv_bwd_kx = the
+ * fused backward + ffc_kernel_ifft_grad_c (dk rows as a complex pair-plane tensor (2, H, N) bf16, `scale`).  One launch each where
+ * a workgroup owns its row. */
+int ffc_conv_fwd_kx(const ffc_plan* plan, const void* xpair, float scale, void* kf_out, const void* u, void* y, void* zsave,
+                    int64_t B, int64_t H, int64_t L, void* stream);
+int ffc_conv_bwd_kx(const ffc_plan* plan, const void* dout, const void* u, const void* kf, void* du, void* ws, const void* zin,
+                    void* outpair, float scale, int64_t B, int64_t H, int64_t L, void* stream);
 /* dk (H, Lk) fp32 = real(iFFT(sum of partials))[:Lk].  Replaces dk_f_out.sum(0) + un-permute +
  * torch.fft.ifft(..., norm='forward').real[..., :k_len] (conv.py:1758-1761, 1861-1864). */
 int ffc_kernel_ifft_grad(const ffc_plan* plan, const void* ws, int64_t B, int64_t H, int64_t Lk, float* dk, void* stream);

@@ -466,3 +466,43 @@ def test_kernel_fft_inside_the_forward_launch(N, L, B, H, gated, Lk, dt):
     finally:
         S.lib().ffcsim_set_fused_k(None, 0)
     assert np.array_equal(kf0, kf1) and np.array_equal(y0, y1)
+
+
+# ---------------------------------------------------------------- the same two fusions in their complex forms (inner convolution of the
+# HBM-level sizes): k_f rows from a pair-plane tensor inside the forward launch, dk rows into a pair-plane tensor out of the backward launch
+@pytest.mark.parametrize("M,B,H", [(32768, 2, 2), (16384, 4, 1), (16384, 2, 2)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_complex_forms_of_the_fused_launches(M, B, H, dt):
+    rng = np.random.default_rng(M + B + dt)
+    x, dd = (rng.standard_normal((B, H, M)).astype(np.float32) for _ in range(2))
+    xk = S.to_bits(rng.standard_normal((2, H, M)).astype(np.float32) * 0.1, dt)
+    nt, _, _, _ = S.plan_info(M, dt)
+    L_ = S.lib()
+    kf0 = np.zeros((H, nt * 1024, 2), np.uint16)
+    assert L_.ffcsim_kernel_fft_c(M, dt, S.p(xk), H, S.p(kf0), ctypes.c_float(0.5)) == 0
+    xb, db = S.to_bits(x, dt), S.to_bits(dd, dt)
+    y0 = S.sim_conv_fwd(M, dt, xb, kf0)
+    kf1 = np.full_like(kf0, 0x7fc0 if dt == 0 else 0x7e00)
+    L_.ffcsim_set_fused_kx(S.p(xk), ctypes.c_float(0.5))
+    try:
+        y1 = S.sim_conv_fwd(M, dt, xb, kf1)
+    finally:
+        L_.ffcsim_set_fused_kx(None, ctypes.c_float(1.0))
+    assert np.array_equal(kf0, kf1) and np.array_equal(y0, y1)
+    # backward: slabs + ffc_kernel_ifft_grad_c against the tail's pair-plane output
+    upw = L_.ffcsim_upw(M)
+    ws = np.full(upw * H * nt * 2048, np.nan, np.float32)
+    du0 = np.zeros_like(xb)
+    nslab = L_.ffcsim_conv_bwd(M, dt, S.p(db), S.p(xb), S.p(kf0), None, None, S.p(du0), None, None, S.p(ws), B, H, M, 1)
+    assert nslab > 0
+    out0 = np.zeros((2, H, M), np.uint16)
+    assert L_.ffcsim_kernel_ifft_grad_c(M, S.p(ws), nslab, H, S.p(out0), ctypes.c_float(0.25)) == 0
+    out1 = np.full((2, H, M), 0x7fc0, np.uint16)
+    du1 = np.zeros_like(xb); ws1 = np.full_like(ws, np.nan)
+    L_.ffcsim_set_fused_dkpair(S.p(out1), ctypes.c_float(0.25))
+    try:
+        assert L_.ffcsim_conv_bwd(M, dt, S.p(db), S.p(xb), S.p(kf0), None, None, S.p(du1), None, None, S.p(ws1), B, H, M, 1) > 0
+    finally:
+        L_.ffcsim_set_fused_dkpair(None, ctypes.c_float(1.0))
+    assert np.array_equal(du0, du1) and np.isnan(ws1).all()
+    assert rel(S.from_bits(out1, 0), S.from_bits(out0, 0).astype(np.float64)) < 2e-3
