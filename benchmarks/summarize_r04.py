@@ -64,7 +64,7 @@ def pmc(prefix, kernel_sub, out_name, title, alg_mb, alg_note):
     print(open(f"{P}/{out_name}").read()[-900:])
 
 
-pmc("c", "conv_kernel", "r04_pmc_conv_kernel.txt", "benchmarks/prof_step_kernels.py fwd: conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> training forward (stores the spectra)",
-    906 + 805, "u 403 + y 403 + k_f 101 + saved spectra 805")
-pmc("b", "bwd_kernel", "r04_pmc_bwd_kernel.txt", "benchmarks/prof_step_kernels.py bwd: bwd_kernel<Geo<32,32,32>,bf16,HALF,ZM=1> fused backward on saved spectra (dout rows by LDS-DMA)", 1107 + 805,
-    "dout 403 + du 403 + k_f 101 + dk_f 201 + saved spectra 805 (u itself is not read any more)")
+pmc("c", "conv_kernel", "r04_pmc_conv_kernel.txt", "benchmarks/prof_step_kernels.py fwd: conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> training forward incl. k -> k_f of the head (stores the spectra)",
+    906 + 805 + 50, "u 403 + y 403 + k_f written and read 101 + k 50 + saved spectra 805")
+pmc("b", "bwd_kernel", "r04_pmc_bwd_kernel.txt", "benchmarks/prof_step_kernels.py bwd: bwd_kernel<Geo<32,32,32>,bf16,HALF,ZM=1> fused backward on saved spectra incl. the dk tail (dout rows by LDS-DMA)", 906 + 50 + 805,
+    "dout 403 + du 403 + k_f 101 + dk 50 (fp32; the dk_f sums never leave the registers) + saved spectra 805")
