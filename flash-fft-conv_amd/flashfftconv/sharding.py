@@ -324,10 +324,13 @@ class _BigOps:
     """GPU backend of the B-shard for the HBM-level sizes (fft >= 262144): the exchanged tensors are the k_f / dk_f rows of
     the inner size, `rows` per head (head-major), so the head partition carries over as a row partition."""
 
-    def __init__(self, mod, device):
+    def __init__(self, mod, device, Lmax=None):
         from . import conv as C, bigfft
         self.C, self.mod = C, mod
-        factors, self.M = bigfft.BIG_FACTORS[mod.seqlen]
+        # the factorisation the single-rank module would pick for these lengths (ADVICE r03: fft 2M / 4M take the one-level
+        # 64 x / 128 x 32768 form when every row fits N/2 / N/4); every rank sees the same lengths, so the ranks agree
+        self.fac = bigfft.choose(mod.seqlen, Lmax, C._TorchOps) if Lmax is not None else bigfft.BIG_FACTORS[mod.seqlen]
+        factors, self.M = self.fac
         self.rows = 1
         for n0 in factors:
             self.rows *= n0
@@ -336,30 +339,30 @@ class _BigOps:
         if k.shape[0] == 0:                        # more ranks than heads: an empty shard
             plan = self.mod._get_plan(k.device, self.M)
             return torch.empty(0, plan.kf_elems, 2, dtype=self.mod.dtype, device=k.device)
-        return self.C._big_kernel_fft(self.mod, k)
+        return self.C._big_kernel_fft(self.mod, k, self.fac)
 
     def conv(self, u, kf, pre, post):
-        return self.C._big_forward(self.mod, u, None, pre, post, False, kf)[0]
+        return self.C._big_forward(self.mod, u, None, pre, post, False, kf, self.fac)[0]
 
     def conv_keep(self, u, kf, pre, post):
         keep = bool(self.mod.save_spectrum) and self.C._spectrum_budget_ok(
             ((u.shape[0] + 1) // 2) * u.shape[1] * self.mod.seqlen * (12 if pre is not None else 8), u.device, self.mod.save_spectrum)
         try:
-            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, keep, kf)
+            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, keep, kf, self.fac)
         except torch.cuda.OutOfMemoryError:      # same retry as the single-rank module
             if not keep:
                 raise
-            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, False, kf)
+            out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, False, kf, self.fac)
         return out, kept
 
     def backward(self, dout, u, kf, pre, post, kept=None):
-        du, dkf, dpre, dpost = self.C._big_backward(self.mod, dout, u, kf, pre, post, 0, kept, True)
+        du, dkf, dpre, dpost = self.C._big_backward(self.mod, dout, u, kf, pre, post, 0, kept, True, self.fac)
         return du, dpre, dpost, dkf
 
     def dk_from_dkf(self, dkf, Lk):
         if dkf.shape[0] == 0:
             return torch.empty(0, Lk, dtype=torch.float32, device=dkf.device)
-        return self.C._big_dk_from_dkf(self.mod, dkf, Lk)
+        return self.C._big_dk_from_dkf(self.mod, dkf, Lk, self.fac)
 
 
 def head_groups(H, world, ngroups):
@@ -526,7 +529,12 @@ class BatchShardedFFTConv(torch.nn.Module):
         if mode == "recompute":
             kk = _AllReduceGrad.apply(k, self.group)
             return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
-        ops = self._ops if self._ops is not None else (_BigOps if self.conv._big else _HipOps)(self.conv, u.device)
+        if self._ops is not None:
+            ops = self._ops
+        elif self.conv._big:
+            ops = _BigOps(self.conv, u.device, max(u.shape[-1], k.shape[-1]))
+        else:
+            ops = _HipOps(self.conv, u.device)
         training = self.conv.training if hasattr(self.conv, "training") else True
         keep = training and torch.is_grad_enabled()      # spectra are only worth storing when a graph is being recorded
         world = dist.get_world_size(self.group)

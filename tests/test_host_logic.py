@@ -1,0 +1,55 @@
+"""Host-side logic that needs no GPU: the memory budget of the saved spectra (flashfftconv/conv.py _spectrum_budget_ok), the head
+groups of the pipelined B-shard, the frequency map of the HBM-level sizes against a brute-force statement of the level algebra."""
+import os, sys
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flash-fft-conv_amd"))
+
+
+def test_spectrum_budget_is_self_limiting(monkeypatch):
+    from flashfftconv import conv as C
+    free = {"v": 80 << 30}
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda idx=None: (free["v"], 288 << 30))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda idx=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda idx=None: 0)
+    C._free_cache.clear()
+    dev = torch.device("cuda", 0)
+    assert C._spectrum_budget_ok(1 << 20, dev)                     # small requests never ask the driver
+    assert C._spectrum_budget_ok(9 << 30, dev)                     # 9 GB of 80 GB free: within 1/8
+    assert not C._spectrum_budget_ok(11 << 30, dev)                # more than 1/8 of what is left (71 GB)
+    assert C._spectrum_budget_ok(11 << 30, dev, "always")          # "always" skips the test
+    # layer after layer (cached figure, requests subtracted): the total stays below the memory that was free at the start
+    C._free_cache.clear()
+    granted, left = 0, 80 << 30
+    for _ in range(200):
+        n = 2 << 30
+        if C._spectrum_budget_ok(n, dev):
+            granted += n
+    assert granted < (80 << 30) and granted >= 60 << 30
+    assert not C._spectrum_budget_ok(2 << 30, dev)
+
+
+@pytest.mark.parametrize("H,world,ng", [(768, 8, 2), (111, 8, 2), (5, 2, 2), (16, 8, 4), (3, 8, 2)])
+def test_head_groups_partition_the_heads(H, world, ng):
+    from flashfftconv.sharding import head_groups, head_range
+    groups = head_groups(H, world, ng)
+    assert groups[0][0] == 0 and groups[-1][1] == H and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+    owned = []
+    for (g0, g1) in groups:
+        for r in range(world):
+            s, e = head_range(g1 - g0, r, world)
+            owned += list(range(g0 + s, g0 + e))
+    assert owned == list(range(H))
+
+
+@pytest.mark.parametrize("N,fac", [(65536, ((16,), 4096)), (4194304, ((16, 16), 16384)), (4194304, ((128,), 32768)), (2097152, ((64,), 32768))])
+def test_row_freq_is_a_bijection_onto_the_spectrum(N, fac):
+    """every natural frequency of the N-point spectrum sits in exactly one (inner row, inner frequency)"""
+    from flashfftconv import bigfft as BG
+    offs, stride = BG.row_freq(N, fac)
+    M = fac[1]
+    assert len(offs) * M == N and stride * M == N
+    f = (np.asarray(offs, np.int64)[:, None] + stride * np.arange(M, dtype=np.int64)[None, :]) % N
+    assert np.array_equal(np.sort(f.ravel()), np.arange(N))

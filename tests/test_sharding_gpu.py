@@ -38,7 +38,8 @@ def _body(rank, world, port, q):
     ok = {}
     dev = torch.device("cuda", 0)
     for (N, B, H, L, gated) in ((4096, 4, 16, 2048, False), (32768, 4, 10, 16384, True), (1024, 8, 7, 1024, False),
-                                (65536, 4, 6, 32768, False), (262144, 4, 6, 131072, False), (524288, 4, 4, 262144, True)):
+                                (65536, 4, 6, 32768, False), (262144, 4, 6, 131072, False), (524288, 4, 4, 262144, True),
+                                (2097152, 2, 2, 524288, False)):      # one level of 64 x 32768 (L <= N/2), also in the B-shard (round 4)
         torch.manual_seed(7)                      # same inputs on both ranks
         dt = torch.bfloat16
         mk = lambda: torch.randn(B, H, L, device=dev).to(dt)
