@@ -163,7 +163,7 @@ int ffc_debug_peaks(double* copy_GBs, double* mfma_TFLOPs) {
 }
 // (ffc_conv_fwd_k / ffc_conv_bwd_k, the module's one call per direction, live next to the launchers they drive: ffc_k_conv.hip,
 // ffc_k_bwd.hip)
-int ffc_version(void) { return 101; }
+int ffc_version(void) { return 102; }
 const char* ffc_last_error(void) { return g_err.c_str(); }
 
 // (Re-)read the tuning knobs from the environment into the plan.  Called once by ffc_plan_create; A/B tuning scripts call

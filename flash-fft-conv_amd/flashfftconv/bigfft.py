@@ -74,22 +74,26 @@ def inner_sfwd(M):
     return 2.0 ** (-((lg + 1) // 2))
 
 
-def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None, fac=None):
-    """x: (B_valid, H, L) long-side tensor -> (2*npair, H*prod(N0), M) pair-plane tensor.  fac: choose(N, ...) (default: BIG_FACTORS)"""
+def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None, fac=None, lf32=None):
+    """x: (B_valid, H, L) long-side tensor -> (2*npair, H*prod(N0), M) pair-plane tensor.  fac: choose(N, ...) (default: BIG_FACTORS).
+    lf32: x is fp32 (the filter k); the first level multiplies by this power of two and rounds to dt itself (ops.LONG_F32)."""
     factors, M = fac or BIG_FACTORS[N]
     npair = (B_valid + 1) // 2
     Hx, nlev, Llong, bv = H, N, L, B_valid
     for i, n0 in enumerate(factors):
         mi = nlev // n0
         out = ops.empty_pair(dt, 2 * npair, Hx * n0, mi)
-        ops.outer(dt, n0, True, x, out, gate if i == 0 else None, bv, npair, Hx, mi, Llong, level_scale(n0))
+        if i == 0 and lf32 is not None:
+            ops.outer(dt, n0, True, x, out, gate, bv, npair, Hx, mi, Llong, level_scale(n0), lf32=lf32)
+        else:
+            ops.outer(dt, n0, True, x, out, gate if i == 0 else None, bv, npair, Hx, mi, Llong, level_scale(n0))
         x, Hx, nlev, Llong, bv = out, Hx * n0, mi, mi, 2 * npair
     return x
 
 
-def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None, fac=None):
+def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None, fac=None, lf32=False):
     """y: (2*npair, H*prod(N0), M) -> out (B_valid, H, L) (written in place).  `shared` caches the
-    intermediate of the two-level case so several gated outputs reuse it."""
+    intermediate of the two-level case so several gated outputs reuse it.  lf32: `out` is fp32 (dk), written by the last level."""
     factors, M = fac or BIG_FACTORS[N]
     npair = y.shape[0] // 2
     Hx = H
@@ -102,7 +106,9 @@ def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None, fa
         Hx //= n0
         nlev *= n0
         sc = 1.0 / (n0 * level_scale(n0))
-        if i == 0:
+        if i == 0 and lf32:
+            ops.outer(dt, n0, False, cur, out, gate, B_valid, npair, Hx, nlev // n0, L, sc, lf32=1.0)
+        elif i == 0:
             ops.outer(dt, n0, False, cur, out, gate, B_valid, npair, Hx, nlev // n0, L, sc)
         else:
             if shared is not None and "mid" in shared:
@@ -124,12 +130,31 @@ def prod_scale(N, fac=None):
     return s
 
 
+def _k_levels(ops, dt, N, k, H, Lk, pre, fac):
+    """the levels over the filter k (H, Lk) fp32: the first level reads the fp32 rows itself (prescale and rounding to dt in its row
+    load, round 4) where the backend can (ops.LONG_F32); otherwise a cast pass in front (ops.to_dtype_rows)"""
+    if getattr(ops, "LONG_F32", False):
+        return levels_forward(ops, dt, N, ops.f32_rows(k, H, Lk), 1, H, Lk, None, fac, lf32=pre)
+    return levels_forward(ops, dt, N, ops.to_dtype_rows(dt, k, H, Lk, pre), 1, H, Lk, None, fac)
+
+
+def _dk_levels(ops, N, y, H, Lk, fac):
+    """complex rows (2, H*prod(N0), M) bf16 -> dk (H, Lk) fp32 through the inverse levels; the last one writes fp32 itself (ops.LONG_F32)"""
+    BF = ops.BF16
+    if getattr(ops, "LONG_F32", False):
+        out = ops.empty_f32(1, H, Lk)
+        levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac, lf32=True)
+        return out[0]
+    out = ops.empty_pair(BF, 1, H, Lk)
+    levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac)
+    return ops.to_float_rows(out, H, Lk)
+
+
 def kernel_fft(ops, dt, N, k, H, Lk, fac=None):
     """k (H, Lk) fp32 -> inner k_f rows (H*prod(N0), M-internal), unscaled K_f."""
     factors, M = fac or BIG_FACTORS[N]
     pre = ops.k_prescale(dt)                         # 2^8 in fp16 mode (k's energy sits in a few taps)
-    kx = ops.to_dtype_rows(dt, k, H, Lk, pre)        # (1, H, Lk) dtype
-    x = levels_forward(ops, dt, N, kx, 1, H, Lk, None, fac)
+    x = _k_levels(ops, dt, N, k, H, Lk, pre, fac)
     hp = x.shape[1]
     return ops.kfft_c(dt, M, x, hp, 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre))
 
@@ -139,8 +164,7 @@ def kernel_rows(ops, dt, N, k, H, Lk, fac=None):
     unscaled k_f of kernel_fft -- for callers that run that last transform inside their convolution launch (ffc_conv_fwd_kx)"""
     factors, M = fac or BIG_FACTORS[N]
     pre = ops.k_prescale(dt)
-    kx = ops.to_dtype_rows(dt, k, H, Lk, pre)
-    return levels_forward(ops, dt, N, kx, 1, H, Lk, None, fac), 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre)
+    return _k_levels(ops, dt, N, k, H, Lk, pre, fac), 1.0 / (inner_sfwd(M) * prod_scale(N, fac) * pre)
 
 
 def dk_pair_scale(N, fac=None):
@@ -151,10 +175,7 @@ def dk_pair_scale(N, fac=None):
 
 def dk_from_pair(ops, N, y, H, Lk, fac=None):
     """complex rows of the inverted inner dk_f, (2, H*prod(N0), M) bf16 -> dk (H, Lk) fp32: the levels of dk_from_slabs"""
-    BF = ops.BF16
-    out = ops.empty_pair(BF, 1, H, Lk)
-    levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac)
-    return ops.to_float_rows(out, H, Lk)
+    return _dk_levels(ops, N, y, H, Lk, fac)
 
 
 def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None, fac=None):
@@ -167,6 +188,4 @@ def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None, fac=None):
     BF = ops.BF16
     sc = 1.0 / (inner_sfwd(M) * prod_scale(N, fac))
     y = ops.dkifft_c(M, ws, Bp, hp, sc) if nslab is None else ops.dkifft_c(M, ws, Bp, hp, sc, nslab)     # (2, hp, M) bf16
-    out = ops.empty_pair(BF, 1, H, Lk)
-    levels_inverse(ops, BF, N, y, out, 1, H, Lk, None, None, fac)
-    return ops.to_float_rows(out, H, Lk)
+    return _dk_levels(ops, N, y, H, Lk, fac)

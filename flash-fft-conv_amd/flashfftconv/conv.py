@@ -8,6 +8,7 @@ Semantics: y = iFFT(FFT(u, N) * FFT(k, N)).real[..., :L] with N = seqlen (refere
 tests/test_flashfftconv.py:5-13).  The reference's 4.9 KLoC `if seqlen == ...` dispatch
 (conv.py:563-4958) collapses to one table-driven plan inside the HIP library."""
 import ctypes
+import math
 import re
 import threading
 import torch
@@ -249,20 +250,35 @@ class _TorchOps:
 
     HAS_128 = True      # factor 128 as 4 passes of the 32-point kernel (bigfft.choose)
 
-    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+    # the levels read the fp32 filter / write the fp32 dk themselves (no cast kernels around them); FFC_BIG_LONG_F32=0: A/B switch
+    LONG_F32 = _os.environ.get("FFC_BIG_LONG_F32", "1") != "0"
+
+    def f32_rows(self, k, H, Lk):
+        return k.detach().reshape(1, H, Lk).to(torch.float32).contiguous()
+
+    def empty_f32(self, Bp, Hx, n):
+        return torch.empty(Bp, Hx, n, dtype=torch.float32, device=self.device)
+
+    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale, lf32=None):
+        dcode = _DT[dt]
+        if lf32 is not None:       # fp32 long side: | 16, forward prescale 2^e in bits 8..15 (csrc/ffc_k_big.hip decode_dtype)
+            e = int(round(math.log2(lf32)))
+            assert 2.0 ** e == lf32 and (fwd or e == 0)
+            assert (inp if fwd else out).dtype == torch.float32
+            dcode |= 16 | (e << 8)
         if n0 in (64, 128):
             R = n0 // 32
             pr = self._plan(32768 * R)      # the R-pass plan: its per-pass outer-digit tables are the matrices of the passes
             if _ONE_LAUNCH_LEVEL:       # all R passes in one launch (long side read / written once)
-                _lib.check(_lib.lib().ffc_outer_pass_all(pr.handle, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
+                _lib.check(_lib.lib().ffc_outer_pass_all(pr.handle, dcode, int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
                                                          npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_all")
                 return
             for c in range(R):
-                _lib.check(_lib.lib().ffc_outer_pass_r(pr.handle, c, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
+                _lib.check(_lib.lib().ffc_outer_pass_r(pr.handle, c, dcode, int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
                                                        npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_r")
             return
         p16, p32 = self._plan(16384), self._plan(32768)
-        _lib.check(_lib.lib().ffc_outer_pass(p16.handle, p32.handle, n0, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(out),
+        _lib.check(_lib.lib().ffc_outer_pass(p16.handle, p32.handle, n0, dcode, int(fwd), _lib.ptr(inp), _lib.ptr(out),
                                              _lib.ptr(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale),
                                              _lib.stream_ptr()), "ffc_outer_pass")
 

@@ -149,6 +149,10 @@ int ffc_kernel_ifft_grad_slabs(const ffc_plan* plan, const void* slabs, int64_t 
  * dir=1: in (Bv,Hin,Llong) real/pair rows [* gate] -> out (2*npair, Hin*n0, Mi) pair-plane complex.
  * dir=0: the inverse map, [* gate] applied to the output.  plan16/plan32: any plans whose outer digit
  * is 16 / 32 (e.g. fft sizes 16384 / 32768), they supply the DFT tile in `dtype`. */
+/* `dtype` of the three level entry points: 0 bf16 / 1 fp16, optionally | 16: the LONG side is fp32 -- dir = 1: `in` is float, multiplied
+ * by 2^e (e = bits 8..15 of dtype, the fp16 mode's prescale of the filter) and rounded once to the 16-bit type in the row load;
+ * dir = 0: `out` is float (the 16-bit results widened).  The filter k and its gradient dk pass through the levels without cast
+ * kernels this way.  Gates stay 16-bit. */
 int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int dtype, int dir, const void* in, void* out,
                    const void* gate, int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale,
                    void* stream);

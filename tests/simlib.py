@@ -125,7 +125,19 @@ class SimOps:
     HAS_128 = True
     one_launch = True
 
-    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale):
+    LONG_F32 = True      # the levels read the fp32 filter / write the fp32 dk themselves (set False: cast passes around them)
+
+    def f32_rows(self, k, H, Lk):
+        return np.ascontiguousarray(np.asarray(k, np.float32).reshape(1, H, Lk))
+
+    def empty_f32(self, Bp, Hx, n):
+        return np.full((Bp, Hx, n), np.nan, np.float32)
+
+    def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale, lf32=None):
+        if lf32 is not None:       # the library's dtype flags (csrc/ffc_k_big.hip decode_dtype)
+            e = int(round(np.log2(lf32)))
+            assert 2.0 ** e == lf32 and (inp if fwd else out).dtype == np.float32
+            dt = dt | 16 | (e << 8)
         if n0 in (64, 128) and self.one_launch:      # all R passes in one workgroup run (ffc_outer_pass_all)
             rc = lib().ffcsim_big_outer_all(n0 // 32, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale))
             assert rc == 0, rc

@@ -453,3 +453,29 @@ def test_hip_graph_capture(N, B, H, L):
         torch.cuda.synchronize()
         assert torch.equal(y, mod(u, k))
         assert not torch.equal(y, ref)
+
+
+@pytest.mark.parametrize("N,dtype,B,H,L", [(262144, torch.float16, 2, 3, 100004), (524288, torch.bfloat16, 2, 2, 262144),
+                                           (4194304, torch.bfloat16, 1, 2, 1048576), (4194304, torch.float16, 1, 1, 1500000)])
+def test_levels_take_the_fp32_filter_and_return_fp32_dk(N, dtype, B, H, L):
+    """round 4: the first level over the filter reads the fp32 rows itself and the last level of dk writes fp32 (BigArgs::lf32) -- no
+    cast kernels around the levels; results bit for bit those of the cast passes (FFC_BIG_LONG_F32 = 0 form), ragged lengths included."""
+    from flashfftconv import FlashFFTConv, conv as C
+    torch.manual_seed(N + L)
+    dev = torch.device("cuda", 0)
+    u, dout = (torch.randn(B, H, L, device=dev).to(dtype) for _ in range(2))
+    k = torch.randn(H, L, device=dev) * 0.05
+    mod = FlashFFTConv(N, dtype=dtype).to(dev)
+    res = []
+    prev = C._TorchOps.LONG_F32
+    try:
+        for flag in (True, False):
+            C._TorchOps.LONG_F32 = flag
+            uu, kk = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
+            y = mod(uu, kk)
+            res.append((y.detach(),) + torch.autograd.grad(y, (uu, kk), dout))
+    finally:
+        C._TorchOps.LONG_F32 = prev
+    for a, b, name in zip(res[0], res[1], ("out", "du", "dk")):
+        assert torch.equal(a, b), (name, (a.float() - b.float()).abs().max().item())
+    assert res[0][2].dtype == torch.float32

@@ -506,3 +506,37 @@ def test_complex_forms_of_the_fused_launches(M, B, H, dt):
         L_.ffcsim_set_fused_dkpair(None, ctypes.c_float(1.0))
     assert np.array_equal(du0, du1) and np.isnan(ws1).all()
     assert rel(S.from_bits(out1, 0), S.from_bits(out0, 0).astype(np.float64)) < 2e-3
+
+
+@pytest.mark.parametrize("N,fac,Lk,dt", [(65536, ((16,), 4096), 40000, 0), (131072, ((32,), 4096), 131072, 1), (131072, ((32,), 4096), 70001, 0),
+                                         (262144, ((64,), 4096), 100000, 1), (524288, ((128,), 4096), 131072, 0),
+                                         (1048576, ((16, 16), 4096), 300004, 1)])
+def test_levels_read_fp32_filter_and_write_fp32_dk(N, fac, Lk, dt):
+    """BigArgs::lf32 (round 4): the first forward level reads the fp32 filter itself (prescale 2^8 in fp16 mode, one rounding to the
+    16-bit type in its row load) and the last inverse level writes dk as fp32 -- bit for bit what the cast passes around the levels
+    produced (ops.to_dtype_rows / to_float_rows), for the plain levels (16, 32), the R-pass levels (64, 128: one launch and one
+    launch per pass), two levels, ragged lengths (element-wise accesses) and both dtypes."""
+    from flashfftconv import bigfft as BG
+    rng = np.random.default_rng(N + Lk)
+    H = 2
+    k = (rng.standard_normal((H, Lk)) * 0.05).astype(np.float32)
+    new, old = S.SimOps(), S.SimOps()
+    old.LONG_F32 = False
+    x_new, sc_new = BG.kernel_rows(new, dt, N, k, H, Lk, fac)
+    x_old, sc_old = BG.kernel_rows(old, dt, N, k, H, Lk, fac)
+    assert sc_new == sc_old and np.array_equal(x_new, x_old)
+    if fac[0][0] in (64, 128):
+        per_pass = S.SimOps(); per_pass.one_launch = False
+        assert np.array_equal(BG.kernel_rows(per_pass, dt, N, k, H, Lk, fac)[0], x_old)
+    # dk side: any complex rows will do (bf16 arithmetic whatever the module dtype)
+    rows = 1
+    for n0 in fac[0]:
+        rows *= n0
+    y = S.to_bits(rng.standard_normal((2, H * rows, fac[1])).astype(np.float32), 0)
+    dk_new = BG.dk_from_pair(new, N, y, H, Lk, fac)
+    dk_old = BG.dk_from_pair(old, N, y, H, Lk, fac)
+    assert dk_new.dtype == np.float32 and dk_new.shape == (H, Lk) and not np.isnan(dk_new).any()
+    assert np.array_equal(dk_new, dk_old)
+    if fac[0][0] in (64, 128):      # one launch per pass: passes c > 0 add to the stored fp32 rows (values of the 16-bit type, as before)
+        pp_old = S.SimOps(); pp_old.one_launch = False; pp_old.LONG_F32 = False
+        assert np.array_equal(BG.dk_from_pair(per_pass, N, y, H, Lk, fac), BG.dk_from_pair(pp_old, N, y, H, Lk, fac))
