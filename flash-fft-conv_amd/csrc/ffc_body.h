@@ -122,6 +122,14 @@ struct Body {
 #pragma unroll
     for (int q = 0; q < 6; q++) B::pin(m.w[q / 3][q % 3]);
   }
+  // the same loads without the pins: issued early (ffc_big.h run<>), consumed -- and waited for -- where the matrix is first used
+  static FFC_FN void load_mat_issue(Mat& m, const uint8_t* p, i32 lane) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      U4 v = B::g_r128(p, lane + q * 64);
+      m.w[q / 3][q % 3] = B::w4(v.x, v.y, v.z, v.w);
+    }
+  }
   static FFC_FN void load_ct16(CT16& c, const uint8_t* p, i32 lane) {
 #pragma unroll
     for (int rr = 0; rr < 8; rr++) {
@@ -416,9 +424,87 @@ struct Body {
       }
     }
   }
+  // Gated rows on the 16-byte path (round 4).  The gate (and side-product) rows used to be loaded where they are multiplied in, one
+  // chunk at a time: load, s_waitcnt vmcnt(0), multiply, next chunk -- 16 memory round trips in a row per pair and wave, each
+  // also waiting for every other load in flight (ISA of the gated kernels; the ungated path had its 16 row loads batched since round 1).
+  // Now the loads of GATE_BATCH chunks (both planes) are issued together ahead of the work on them.  The batch is a per-
+  // translation-unit constant: the forward kernels take all chunks of the wave's slice, the backward kernels (128-VGPR budget) two.
+#ifndef FFC_GATE_BATCH
+#define FFC_GATE_BATCH 4
+#endif
+  template <int NC, int I0>
+  static FFC_FN void rows_store_g(const ConvArgs& a, int h, int pq, Unit un, const RowRegsT<NC>& X) {
+    constexpr int GB = FFC_GATE_BATCH <= 0 ? 1 : (NC < FFC_GATE_BATCH ? NC : FFC_GATE_BATCH);
+    static_assert(NC % GB == 0, "gate batch");
+    const i32 lane = B::opaque(B::lane());
+    const int fast = a.stream ? 2 : 1;
+    const bool hasg = a.pregate != nullptr, hasa = a.aux_in != nullptr;
+#pragma unroll
+    for (int ib = 0; ib < NC; ib += GB) {
+      U4 G[GB][2], A[GB][2];
+#pragma unroll
+      for (int jj = 0; jj < GB; jj++) {
+        const int i = ib + jj + I0;
+        i32 idx = lane + i * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+        if (GEO::OUTER && ((i * 64) / CPR) * GEO::Mi >= a.L) continue;      // chunk beyond L: zeros, nothing to gate
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          if constexpr (GEO::OUTER) {
+            const int b = 2 * pq + pl;
+            const bool ok = b < a.B;
+            const i32 n = row * GEO::Mi + m;
+            if (hasg) G[jj][pl] = gload8((const uint16_t*)a.pregate + row_off(b, ok, a.sbg, h, a.L), n, a.L, fast, ok);
+            if (hasa) A[jj][pl] = gload8((const uint16_t*)a.aux_in + row_off(b, ok, a.sbai, h, a.L), n, a.L, fast, ok);
+          } else {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            if (hasg) G[jj][pl] = gload8_rows((const uint16_t*)a.pregate, b, h, a, a.sbg, m, fast, b < a.B);
+            if (hasa) A[jj][pl] = gload8_rows((const uint16_t*)a.aux_in, b, h, a, a.sbai, m, fast, b < a.B);
+          }
+        }
+      }
+      B::sched_fence();
+#pragma unroll
+      for (int jj = 0; jj < GB; jj++) {
+        const int ii = ib + jj, i = ii + I0;
+        i32 idx = lane + i * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+        pred sw;
+        i32 off = pair_off(row, m, &sw) + un.eb;
+        const bool beyond = GEO::OUTER && ((i * 64) / CPR) * GEO::Mi >= a.L;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          U4 v = X.v[ii][pl];
+          if (GEO::OUTER) {        // masks of the unconditional fast-path loads
+            pred ok = ((row * GEO::Mi + m) < a.L) && ((2 * pq + pl) < a.B);
+            v.x = B::sel(ok, v.x, B::uconst(0)); v.y = B::sel(ok, v.y, B::uconst(0));
+            v.z = B::sel(ok, v.z, B::uconst(0)); v.w = B::sel(ok, v.w, B::uconst(0));
+          }
+          if (hasa && !beyond) {      // side product aux_out = row * aux_in
+            if constexpr (GEO::OUTER) {
+              const int b = 2 * pq + pl;
+              const bool ok = b < a.B;
+              gstore8((uint16_t*)a.aux_out + row_off(b, ok, a.sbao, h, a.L), row * GEO::Mi + m, a.L, fast, ok, mul4(v, A[jj][pl]));
+            } else {
+              i32 b = (row + pq * GEO::G) * 2 + pl;
+              gstore8_rows((uint16_t*)a.aux_out, b, h, a, a.sbao, m, fast, b < a.B, mul4(v, A[jj][pl]));
+            }
+          }
+          if (hasg && !beyond) v = mul4(v, G[jj][pl]);
+          U4 o;
+          o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
+          o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
+          B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+        }
+      }
+    }
+  }
   // (x) pregate, swizzle, write to E
   template <int NC, int I0 = 0>
   static FFC_FN void rows_store(const ConvArgs& a, int h, int pq, Unit un, const RowRegsT<NC>& X) {
+    if constexpr (FFC_GATE_BATCH > 0) {      // (0: A/B builds of the one-load-at-a-time form below)
+      if (a.fast && (a.pregate || a.aux_in)) { rows_store_g<NC, I0>(a, h, pq, un, X); return; }
+    }
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll
@@ -561,8 +647,65 @@ struct Body {
     }
   }
 
+  // output rows with an output gate on the 16-byte path: the gate loads of a batch of chunks first (see rows_store_g)
+  template <int NC>
+  static FFC_FN void rows_out_g(const ConvArgs& a, int h, int pq, Unit un) {
+    constexpr int GB = FFC_GATE_BATCH <= 0 ? 1 : (NC < FFC_GATE_BATCH ? NC : FFC_GATE_BATCH);
+    static_assert(NC % GB == 0, "gate batch");
+    const i32 lane = B::opaque(B::lane());
+    const int fast = a.stream ? 2 : 1;
+#pragma unroll
+    for (int ib = 0; ib < NC; ib += GB) {
+      U4 G[GB][2];
+#pragma unroll
+      for (int jj = 0; jj < GB; jj++) {
+        const int i = ib + jj;
+        i32 idx = lane + i * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          if constexpr (GEO::OUTER) {
+            const int b = 2 * pq + pl;
+            const bool ok = b < a.B;
+            G[jj][pl] = gload8((const uint16_t*)a.postgate + row_off(b, ok, a.sbp, h, a.L), row * GEO::Mi + m, a.L, fast, ok);
+          } else {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            G[jj][pl] = gload8_rows((const uint16_t*)a.postgate, b, h, a, a.sbp, m, fast, b < a.B);
+          }
+        }
+      }
+      B::sched_fence();
+#pragma unroll
+      for (int jj = 0; jj < GB; jj++) {
+        const int i = ib + jj;
+        i32 idx = lane + i * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+        pred sw;
+        i32 off = pair_off(row, m, &sw) + un.eb;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          U4 o = B::lds_r128(off + pl * GEO::PLANE);
+          U4 v;
+          v.x = B::sel(sw, o.z, o.x); v.y = B::sel(sw, o.w, o.y);
+          v.z = B::sel(sw, o.x, o.z); v.w = B::sel(sw, o.y, o.w);
+          v = mul4(v, G[jj][pl]);
+          if constexpr (GEO::OUTER) {
+            const int b = 2 * pq + pl;
+            const bool ok = b < a.B;
+            gstore8((uint16_t*)a.y + row_off(b, ok, a.sby, h, a.L), row * GEO::Mi + m, a.L, fast, ok, v);
+          } else {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            gstore8_rows((uint16_t*)a.y, b, h, a, a.sby, m, fast, b < a.B, v);
+          }
+        }
+      }
+    }
+  }
   template <int NC = NCH>
   static FFC_FN void rows_out(const ConvArgs& a, int h, int pq, Unit un) {
+    if constexpr (FFC_GATE_BATCH > 0) {
+      if (a.fast && a.postgate) { rows_out_g<NC>(a, h, pq, un); return; }
+    }
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
 #pragma unroll

@@ -4,6 +4,12 @@
 // Two units so that the library's longest compile runs as two parallel halves, and so that a profile names the two forms apart
 // (one kernel name averaged saved-spectra and recompute launches).
 #pragma once
+// gated rows: gate loads one chunk (both planes: 2 x 16 bytes per lane in flight) at a time: these kernels run on a 128-VGPR budget next
+// to the 128 accumulation registers; with batches of 2 chunks the allocator reached into a0..a127 (build.py check_agpr), the forward
+// kernels take 4 (ffc_body.h rows_store_g)
+#ifndef FFC_GATE_BATCH
+#define FFC_GATE_BATCH 1
+#endif
 #include "ffc_dev.h"
 using namespace ffc;
 

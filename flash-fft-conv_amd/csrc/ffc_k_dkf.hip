@@ -1,4 +1,7 @@
 // dk_f accumulation kernel (Modes::dkf) + ffc_conv_bwd_dkf.
+#ifndef FFC_GATE_BATCH
+#define FFC_GATE_BATCH 1      // (see ffc_bwd_launch.h)
+#endif
 #include "ffc_dev.h"
 using namespace ffc;
 
