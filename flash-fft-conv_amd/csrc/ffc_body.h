@@ -261,15 +261,42 @@ struct Body {
       B::lds_w128(idx * 16 + lds_off, v, ok);
     }
   }
-  static FFC_FN void setup_tables(const uint8_t* tab, const PlanTabs& t) {
-    if constexpr (GEO::OUTER) {
-      copy_tab(tab + t.mat[0], GEO::L_F1, 6144);
+  // table pieces of this thread: loads from a clamped index (always issued, no exec-masked branch), LDS writes under the predicate
+  static constexpr int TAB_T = GEO::WGW * 64;
+  template <int BYTES>
+  static FFC_FN void tab_issue(const uint8_t* src, U4 (&v)[(BYTES / 16 + TAB_T - 1) / TAB_T]) {
+    const i32 tid = B::lane() + B::wave() * 64;
+#pragma unroll
+    for (int it = 0; it < (BYTES / 16 + TAB_T - 1) / TAB_T; it++) v[it] = B::g_r128(src, B::imin(tid + it * TAB_T, BYTES / 16 - 1));
+  }
+  template <int BYTES>
+  static FFC_FN void tab_commit(int lds_off, const U4 (&v)[(BYTES / 16 + TAB_T - 1) / TAB_T]) {
+    const i32 tid = B::lane() + B::wave() * 64;
+#pragma unroll
+    for (int it = 0; it < (BYTES / 16 + TAB_T - 1) / TAB_T; it++) {
+      i32 idx = tid + it * TAB_T;
+      B::lds_w128(idx * 16 + lds_off, v[it], idx < BYTES / 16);
     }
-    copy_tab(tab + t.mat[1], GEO::L_F2, 6144);
-    copy_tab(tab + t.twin, GEO::L_TW, 8192);
-    if constexpr (GEO::N3 != GEO::N2) copy_tab(tab + t.mat[2], GEO::L_F3, 6144);
-    if constexpr (GEO::TW2_SEP) copy_tab(tab + t.twin2, GEO::L_TW2, 8192);
-    if constexpr (GEO::HAS_SP) copy_tab(tab + t.mat_sp, GEO::L_FS, 3072);
+  }
+  // Round 4: every table's loads are requested first, then written to LDS (copy_tab one table after the other put each load into
+  // its own branch followed by s_waitcnt vmcnt(0): 3 .. 6 L2 round trips in a row at the start of every workgroup -- a tenth of the
+  // run time of the short-sequence launches).
+  static FFC_FN void setup_tables(const uint8_t* tab, const PlanTabs& t) {
+    U4 f1[(6144 / 16 + TAB_T - 1) / TAB_T], f2[(6144 / 16 + TAB_T - 1) / TAB_T], f3[(6144 / 16 + TAB_T - 1) / TAB_T],
+       tw[(8192 / 16 + TAB_T - 1) / TAB_T], tw2[(8192 / 16 + TAB_T - 1) / TAB_T], fs[(3072 / 16 + TAB_T - 1) / TAB_T];
+    if constexpr (GEO::OUTER) tab_issue<6144>(tab + t.mat[0], f1);
+    tab_issue<6144>(tab + t.mat[1], f2);
+    tab_issue<8192>(tab + t.twin, tw);
+    if constexpr (GEO::N3 != GEO::N2) tab_issue<6144>(tab + t.mat[2], f3);
+    if constexpr (GEO::TW2_SEP) tab_issue<8192>(tab + t.twin2, tw2);
+    if constexpr (GEO::HAS_SP) tab_issue<3072>(tab + t.mat_sp, fs);
+    B::sched_fence();
+    if constexpr (GEO::OUTER) tab_commit<6144>(GEO::L_F1, f1);
+    tab_commit<6144>(GEO::L_F2, f2);
+    tab_commit<8192>(GEO::L_TW, tw);
+    if constexpr (GEO::N3 != GEO::N2) tab_commit<6144>(GEO::L_F3, f3);
+    if constexpr (GEO::TW2_SEP) tab_commit<8192>(GEO::L_TW2, tw2);
+    if constexpr (GEO::HAS_SP) tab_commit<3072>(GEO::L_FS, fs);
     if (B::wave() == 0) {      // tile counters of the dynamically scheduled phase B (64 bytes)
       U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
       B::lds_w128(B::lane() * 16 + GEO::L_DYN, z, B::lane() < 4);
@@ -648,9 +675,12 @@ struct Body {
   }
 
   // output rows with an output gate on the 16-byte path: the gate loads of a batch of chunks first (see rows_store_g)
+#ifndef FFC_GATE_BATCH_OUT
+#define FFC_GATE_BATCH_OUT FFC_GATE_BATCH      // (the output side holds no prefetched rows: the backward kernels afford a larger batch here)
+#endif
   template <int NC>
   static FFC_FN void rows_out_g(const ConvArgs& a, int h, int pq, Unit un) {
-    constexpr int GB = FFC_GATE_BATCH <= 0 ? 1 : (NC < FFC_GATE_BATCH ? NC : FFC_GATE_BATCH);
+    constexpr int GB = FFC_GATE_BATCH_OUT <= 0 ? 1 : (NC < FFC_GATE_BATCH_OUT ? NC : FFC_GATE_BATCH_OUT);
     static_assert(NC % GB == 0, "gate batch");
     const i32 lane = B::opaque(B::lane());
     const int fast = a.stream ? 2 : 1;
@@ -772,36 +802,73 @@ struct Body {
   }
   // rows_in of pass k0: E row n1 = sum_n0 W_R^{n0 k0} (u * pregate)[n0 M + n1 Mi + m]; plane 0 = Re (batch row 2p),
   // plane 1 = Im (row 2p+1).  W_R^{q'} = (-i)^q with q = q' * 4 / R:  (-i)^q (r + i s) = (r,s), (s,-r), (-r,-s), (-s,r).
+  // (round 4: the loads of a batch of chunks -- rows and, gated, their gates -- are issued together; before, each chunk's two loads
+  // sat between the previous chunk's LDS writes and an `unroll 1` loop the scheduler cannot move loads across: 8 round trips per pass)
+  static constexpr int GB_RP = FFC_GATE_BATCH <= 0 ? 1 : FFC_GATE_BATCH;
   template <int NC>
   static FFC_FN void rows_in_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    constexpr int GB = NC < GB_RP ? NC : GB_RP;
+    static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
     const int n0max = (a.L + GEO::N - 1) / GEO::N;
+    const bool hasg = a.pregate != nullptr;
+    int64_t ru[2], rg[2]; bool okb[2];
 #pragma unroll
-    for (int i = 0; i < NC; i++) {
-      i32 idx = lane + i * 64;
-      i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
-      pred sw;
-      i32 off = pair_off(row, m, &sw) + un.eb;
-      i32 n = row * GEO::Mi + m;
-      U4 acc[2];
-      acc[0] = load_gated(a, h, 2 * pq, n, fast);
-      acc[1] = load_gated(a, h, 2 * pq + 1, n, fast);
+    for (int pl = 0; pl < 2; pl++) {
+      okb[pl] = (2 * pq + pl) < a.B;
+      ru[pl] = row_off(2 * pq + pl, okb[pl], a.sbu, h, a.L);
+      rg[pl] = row_off(2 * pq + pl, okb[pl], a.sbg, h, a.L);
+    }
+#pragma unroll
+    for (int ib = 0; ib < NC; ib += GB) {
+      U4 acc[GB][2];
 #pragma unroll 1
-      for (int n0 = 1; n0 < n0max; n0++) {
-        U4 w0 = load_gated(a, h, 2 * pq, n + n0 * GEO::N, fast), w1 = load_gated(a, h, 2 * pq + 1, n + n0 * GEO::N, fast);
+      for (int n0 = 0; n0 < n0max; n0++) {
+        U4 W[GB][2], G[GB][2];
+#pragma unroll
+        for (int jj = 0; jj < GB; jj++) {
+          i32 idx = lane + (ib + jj) * 64;
+          i32 n = (idx / CPR) * GEO::Mi + (idx % CPR) * 8 + un.wq * 128 * GEO::S1 + n0 * GEO::N;
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++) {
+            W[jj][pl] = gload8((const uint16_t*)a.u + ru[pl], n, a.L, fast, okb[pl]);
+            if (hasg) G[jj][pl] = gload8((const uint16_t*)a.pregate + rg[pl], n, a.L, fast, okb[pl]);
+          }
+        }
+        B::sched_fence();
         const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
         const float sgr = q < 2 ? 1.0f : -1.0f, sgi = (q == 0 || q == 3) ? 1.0f : -1.0f;
-        if (q & 1) { acc[0] = add4(acc[0], w1, sgr); acc[1] = add4(acc[1], w0, sgi); }
-        else { acc[0] = add4(acc[0], w0, sgr); acc[1] = add4(acc[1], w1, sgi); }
+#pragma unroll
+        for (int jj = 0; jj < GB; jj++) {
+          i32 idx = lane + (ib + jj) * 64;
+          i32 n = (idx / CPR) * GEO::Mi + (idx % CPR) * 8 + un.wq * 128 * GEO::S1 + n0 * GEO::N;
+          U4 w[2];
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++) {      // (u * pregate)[n .. n+7], zero beyond L / for a missing row (load_gated)
+            w[pl] = W[jj][pl];
+            if (fast) w[pl] = mask4(w[pl], (n < a.L) && okb[pl]);
+            if (hasg) w[pl] = mul4(w[pl], G[jj][pl]);
+          }
+          if (n0 == 0) { acc[jj][0] = w[0]; acc[jj][1] = w[1]; }
+          else if (q & 1) { acc[jj][0] = add4(acc[jj][0], w[1], sgr); acc[jj][1] = add4(acc[jj][1], w[0], sgi); }
+          else { acc[jj][0] = add4(acc[jj][0], w[0], sgr); acc[jj][1] = add4(acc[jj][1], w[1], sgi); }
+        }
       }
 #pragma unroll
-      for (int pl = 0; pl < 2; pl++) {
-        const U4& v = acc[pl];
-        U4 o;
-        o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
-        o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
-        B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+      for (int jj = 0; jj < GB; jj++) {
+        i32 idx = lane + (ib + jj) * 64;
+        i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
+        pred sw;
+        i32 off = pair_off(row, m, &sw) + un.eb;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+          const U4& v = acc[jj][pl];
+          U4 o;
+          o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
+          o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
+          B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+        }
       }
     }
   }
@@ -834,9 +901,14 @@ struct Body {
   // (s,-r).  Passes k0 > 0 add to what the SAME wave stored in the earlier passes (its own column slice).
   template <int NC>
   static FFC_FN void rows_out_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    // batches of chunks: the earlier passes' sums (passes k0 > 0) and, on the last pass, the output gate of a batch are requested
+    // together ahead of the work on them (round 4; before: the sums up front in the forward kernels only, the gate chunk by chunk)
+    constexpr int GB = B::LEAN_OUTER ? (NC < GB_RP ? NC : GB_RP) : (NC < 4 ? NC : 4);
+    static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
     const int n0max = (a.L + GEO::N - 1) / GEO::N;
+    const bool add_old = ps.k0 > 0, gate = a.postgate && ps.k0 == ps.R - 1;
     int64_t ro[2], rg[2]; bool okb[2];
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
@@ -847,44 +919,45 @@ struct Body {
 #pragma unroll 1
     for (int n0 = 0; n0 < n0max; n0++) {
       const int q = (n0 * ps.k0 * (4 / ps.R)) & 3;
-      // the earlier passes' sums of this block: all requested up front (a load behind each store would wait out its
-      // latency chunk by chunk: loads may not pass the stores to the same tensor)
-      // (not in the backward kernels: 64 more registers do not fit their 128-VGPR budget)
-      constexpr bool HOIST = !B::LEAN_OUTER;
-      RowRegsT<HOIST ? NC : 1> old;
-      if (HOIST && ps.k0 > 0) {
 #pragma unroll
-        for (int i = 0; i < NC; i++) {
-          i32 idx = lane + i * 64;
+      for (int ib = 0; ib < NC; ib += GB) {
+        U4 old[GB][2], G[GB][2];
+#pragma unroll
+        for (int jj = 0; jj < GB; jj++) {
+          i32 idx = lane + (ib + jj) * 64;
           i32 n = (idx / CPR) * GEO::Mi + (idx % CPR) * 8 + un.wq * 128 * GEO::S1 + n0 * GEO::N;
 #pragma unroll
-          for (int pl = 0; pl < 2; pl++) old.v[i][pl] = gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]);
+          for (int pl = 0; pl < 2; pl++) {
+            if (add_old) old[jj][pl] = gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]);
+            if (gate) G[jj][pl] = gload8((const uint16_t*)a.postgate + rg[pl], n, a.L, fast, okb[pl]);
+          }
         }
-      }
+        B::sched_fence();
 #pragma unroll
-      for (int i = 0; i < NC; i++) {
-        i32 idx = lane + i * 64;
-        i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
-        pred sw;
-        i32 off = pair_off(row, m, &sw) + un.eb;
-        U4 y[2];
+        for (int jj = 0; jj < GB; jj++) {
+          i32 idx = lane + (ib + jj) * 64;
+          i32 row = idx / CPR, m = (idx % CPR) * 8 + un.wq * 128 * GEO::S1;
+          pred sw;
+          i32 off = pair_off(row, m, &sw) + un.eb;
+          U4 y[2];
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-          U4 o = B::lds_r128(off + pl * GEO::PLANE);
-          y[pl].x = B::sel(sw, o.z, o.x); y[pl].y = B::sel(sw, o.w, o.y);
-          y[pl].z = B::sel(sw, o.x, o.z); y[pl].w = B::sel(sw, o.y, o.w);
-        }
-        i32 n = row * GEO::Mi + m + n0 * GEO::N;
+          for (int pl = 0; pl < 2; pl++) {
+            U4 o = B::lds_r128(off + pl * GEO::PLANE);
+            y[pl].x = B::sel(sw, o.z, o.x); y[pl].y = B::sel(sw, o.w, o.y);
+            y[pl].z = B::sel(sw, o.x, o.z); y[pl].w = B::sel(sw, o.y, o.w);
+          }
+          i32 n = row * GEO::Mi + m + n0 * GEO::N;
 #pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-          // plane 0: {r, -s, -r, s}[q], plane 1: {s, r, -s, -r}[q]
-          U4 c = ((q & 1) != 0) == (pl == 0) ? y[1] : y[0];
-          const float sg = pl == 0 ? ((q == 0 || q == 3) ? 1.0f : -1.0f) : (q < 2 ? 1.0f : -1.0f);
-          // the passes' contributions are summed ungated; the output gate multiplies the sum, on the last pass only (the gate
-          // load and its 28 VALU per 8 elements were 20 % of a pass's VALU count when every pass multiplied its own part)
-          if (ps.k0 > 0) c = add4(HOIST ? old.v[HOIST ? i : 0][pl] : gload8((const uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl]), c, sg);
-          if (a.postgate && ps.k0 == ps.R - 1) c = mul4(c, gload8((const uint16_t*)a.postgate + rg[pl], n, a.L, fast, okb[pl]));
-          gstore8((uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl], c);
+          for (int pl = 0; pl < 2; pl++) {
+            // plane 0: {r, -s, -r, s}[q], plane 1: {s, r, -s, -r}[q]
+            U4 c = ((q & 1) != 0) == (pl == 0) ? y[1] : y[0];
+            const float sg = pl == 0 ? ((q == 0 || q == 3) ? 1.0f : -1.0f) : (q < 2 ? 1.0f : -1.0f);
+            // the passes' contributions are summed ungated; the output gate multiplies the sum, on the last pass only (the gate
+            // load and its 28 VALU per 8 elements were 20 % of a pass's VALU count when every pass multiplied its own part)
+            if (add_old) c = add4(old[jj][pl], c, sg);
+            if (gate) c = mul4(c, G[jj][pl]);
+            gstore8((uint16_t*)a.y + ro[pl], n, a.L, fast, okb[pl], c);
+          }
         }
       }
     }

@@ -9,6 +9,7 @@
 // kernels take 4 (ffc_body.h rows_store_g)
 #ifndef FFC_GATE_BATCH
 #define FFC_GATE_BATCH 1
+#define FFC_GATE_BATCH_OUT 2
 #endif
 #include "ffc_dev.h"
 using namespace ffc;
