@@ -63,6 +63,41 @@ def check_agpr(asm_path):
         raise RuntimeError(f"{asm_path}: compiler-allocated accumulation registers ({len(bad)} findings), e.g. {bad[:3]}")
 
 
+# Loads-in-flight audit (round 4).  The HBM-level passes are bandwidth kernels whose speed hangs on every row load of a block being
+# issued before the first one is waited for; run-time switches inside the row loop once put each load into its own branch with a
+# `s_waitcnt vmcnt(0)` behind it (2.95 instead of 4.45 TB/s) and nothing failed.  For the kernels listed here the build checks the
+# device assembly: the longest run of 16-byte global loads with no vmcnt wait, label or branch in between must reach the given length.
+LOAD_RUNS = {"ffc_k_big.hip": [(r"^_Z10big_kernelILi(16|32)ELi[01]ELb[01]E", 16), (r"^_Z14big_all_kernelILi[01]ELb1E", 16)]}
+
+
+def check_load_runs(asm_path, rules):
+    import re
+    kernel, run, best = None, 0, {}
+    with open(asm_path) as fh:
+        for line in fh:
+            t = line.split(";")[0].strip()
+            m = re.match(r"^(_Z\w+):", t)
+            if m:
+                kernel, run = m.group(1), 0
+                continue
+            if kernel is None or not t:
+                continue
+            if t.startswith("global_load_dwordx4"):
+                run += 1
+                best[kernel] = max(best.get(kernel, 0), run)
+            elif re.match(r"^(s_waitcnt.*vmcnt|s_cbranch|s_branch|\.LBB|s_barrier)", t):
+                run = 0
+    bad, seen = [], 0
+    for pat, need in rules:
+        for k, v in best.items():
+            if re.match(pat, k):
+                seen += 1
+                if v < need:
+                    bad.append(f"{k}: longest run of 16-byte loads in flight {v} < {need}")
+    if bad or not seen:
+        raise RuntimeError(f"{asm_path}: loads-in-flight audit: {bad[:4] if bad else 'no kernel matched the rules'}")
+
+
 def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=None):
     """Compile every translation unit for gfx950 in parallel, then link the shared library.
     variant: tuning build with `extra_flags` under lib/variants/<name>/ (A/B runs: FFC_LIB=<that .so>)."""
@@ -86,7 +121,7 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
 
     def compile_one(f):
         # checked translation units keep the device assembly of the SAME compile (-save-temps=obj) for check_agpr
-        checked = f in AGPR_CHECKED
+        checked = f in AGPR_CHECKED or f in LOAD_RUNS
         src = os.path.join(CSRC, f)
         out = os.path.join(obj_dir, f + ".o")
         stem = os.path.splitext(f)[0]
@@ -103,7 +138,10 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
             subprocess.check_call(cmd, cwd=obj_dir)
             if checked and not os.environ.get("FFC_SKIP_AGPR_CHECK"):      # (knock-out timing builds skip the check)
                 try:
-                    check_agpr(asm)
+                    if f in AGPR_CHECKED:
+                        check_agpr(asm)
+                    if f in LOAD_RUNS and not any(x.startswith("-DFFC_KO") for x in fl):
+                        check_load_runs(asm, LOAD_RUNS[f])
                 except Exception:
                     os.remove(out)          # a failed check must not leave an object the next build would link
                     raise
