@@ -805,12 +805,29 @@ struct Body {
   // (round 4: the loads of a batch of chunks -- rows and, gated, their gates -- are issued together; before, each chunk's two loads
   // sat between the previous chunk's LDS writes and an `unroll 1` loop the scheduler cannot move loads across: 8 round trips per pass)
   static constexpr int GB_RP = FFC_GATE_BATCH <= 0 ? 1 : FFC_GATE_BATCH;
+  // The 16-byte / element-wise decision of the multi-pass row functions is made ONCE per call (rows_*_rp_t<NC, FASTP>), not inside every
+  // gload8 (round 4, last change of the round).  With the three-way switch inside, each load of a batch sat in its own flow block whose
+  // merge carries a `s_waitcnt vmcnt(0)` -- load, wait, load, wait ..., 16 round trips per pass and wave in the UNGATED kernels too (ISA
+  // of conv_rp_kernel / conv_kernel<Geo<1,32,32>>); rows_store_g / rows_out_g pass a constant 1 / 2 and never had this.  Same box, bit-
+  // identical (profiles/r04_ab_rp_hoist.txt): fft 65536 B16 H768 forward 1.576 -> 1.241 ms, training forward 1.730 -> 1.383; fft 131072
+  // B8 H768 2.338 -> 1.827 / 2.536 -> 1.951.  Forward kernels only: in the multi-pass BACKWARD kernels the second copy of the row code
+  // overflows the 128-VGPR budget (build audit) -- next: the fast / element-wise split as two kernels (FFC_RP_HOIST=0: the former code).
+#ifndef FFC_RP_HOIST
+#define FFC_RP_HOIST 1
+#endif
   template <int NC>
   static FFC_FN void rows_in_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    if constexpr (FFC_RP_HOIST != 0 && !B::LEAN_OUTER) {
+      if (a.fast) { rows_in_rp_t<NC, true>(a, h, pq, un, ps); return; }
+    }
+    rows_in_rp_t<NC, false>(a, h, pq, un, ps);
+  }
+  template <int NC, bool FASTP>
+  static FFC_FN void rows_in_rp_t(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
     constexpr int GB = NC < GB_RP ? NC : GB_RP;
     static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
-    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
+    const int fast = FASTP ? (a.stream ? 2 : 1) : (a.fast ? (a.stream ? 2 : 1) : 0);
     const int n0max = (a.L + GEO::N - 1) / GEO::N;
     const bool hasg = a.pregate != nullptr;
     int64_t ru[2], rg[2]; bool okb[2];
@@ -901,12 +918,19 @@ struct Body {
   // (s,-r).  Passes k0 > 0 add to what the SAME wave stored in the earlier passes (its own column slice).
   template <int NC>
   static FFC_FN void rows_out_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    if constexpr (FFC_RP_HOIST != 0 && !B::LEAN_OUTER) {
+      if (a.fast) { rows_out_rp_t<NC, true>(a, h, pq, un, ps); return; }
+    }
+    rows_out_rp_t<NC, false>(a, h, pq, un, ps);
+  }
+  template <int NC, bool FASTP>
+  static FFC_FN void rows_out_rp_t(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
     // batches of chunks: the earlier passes' sums (passes k0 > 0) and, on the last pass, the output gate of a batch are requested
     // together ahead of the work on them (round 4; before: the sums up front in the forward kernels only, the gate chunk by chunk)
     constexpr int GB = B::LEAN_OUTER ? (NC < GB_RP ? NC : GB_RP) : (NC < 4 ? NC : 4);
     static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
-    const int fast = a.fast ? (a.stream ? 2 : 1) : 0;
+    const int fast = FASTP ? (a.stream ? 2 : 1) : (a.fast ? (a.stream ? 2 : 1) : 0);
     const int n0max = (a.L + GEO::N - 1) / GEO::N;
     const bool add_old = ps.k0 > 0, gate = a.postgate && ps.k0 == ps.R - 1;
     int64_t ro[2], rg[2]; bool okb[2];
