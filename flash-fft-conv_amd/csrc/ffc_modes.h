@@ -117,7 +117,59 @@ struct Modes : Body<B, GEO, DT> {
       for (int q = 0; q < 8; q++) v[q] = B::as_f32(B::g_r32(base, e0 + q, ok && ((n + q) < lim)));
     }
   }
+  // 16-byte path of k_rows_in: every load of the wave's slice first (clamped, unconditional), then the rounding and the LDS writes.
+  // The loop below it consumes each chunk's two loads before it requests the next chunk's: 8 memory round trips in a row for the
+  // filter row of a head -- in the forward launch that transforms its own filter (kfft_head) that was most of the step's head time.
+  static FFC_FN void k_rows_in_fast(const KfArgs& a, int unit_id, Unit un) {
+    const i32 lane = B::opaque(B::lane());
+    U4 A[BD::NCH], Bq[BD::NCH];
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      // (no skip for chunks beyond Lk: a branch per chunk would put every chunk's loads into a flow block of their own, with a
+      // conservative s_waitcnt at each merge; the clamped index makes such a chunk re-read one 16-byte piece)
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      i32 hd, n;
+      if constexpr (GEO::OUTER) { hd = row * 0 + unit_id; n = row * GEO::Mi + m; }
+      else { hd = row + unit_id * GEO::G; n = m; }
+      i32 hb = B::imin(hd, a.H - 1) * a.Lk;
+      A[i] = B::g_r128(a.k, (hb + B::imin(n, a.Lk - 4)) >> 2);
+      Bq[i] = B::g_r128(a.k, (hb + B::imin(n + 4, a.Lk - 4)) >> 2);
+    }
+    B::sched_fence();
+#pragma unroll
+    for (int i = 0; i < BD::NCH; i++) {
+      i32 idx = lane + i * 64;
+      i32 row = idx / BD::CPR, m = (idx % BD::CPR) * 8 + (GEO::OUTER ? un.wq * 128 * GEO::S1 : 0);
+      pred sw;
+      i32 off = BD::pair_off(row, m, &sw) + un.eb;
+      i32 hd, n;
+      if constexpr (GEO::OUTER) { hd = row * 0 + unit_id; n = row * GEO::Mi + m; }
+      else { hd = row + unit_id * GEO::G; n = m; }
+      U4 o;
+      if (GEO::OUTER && ((i * 64) / BD::CPR) * GEO::Mi >= a.Lk) {
+        o.x = B::uconst(0); o.y = B::uconst(0); o.z = B::uconst(0); o.w = B::uconst(0);
+      } else {
+        pred oka = (hd < a.H) && (n < a.Lk), okb = (hd < a.H) && ((n + 4) < a.Lk);
+        const u32 zz = B::uconst(0);
+        f32 v[8];
+        v[0] = B::as_f32(B::sel(oka, A[i].x, zz)); v[1] = B::as_f32(B::sel(oka, A[i].y, zz));
+        v[2] = B::as_f32(B::sel(oka, A[i].z, zz)); v[3] = B::as_f32(B::sel(oka, A[i].w, zz));
+        v[4] = B::as_f32(B::sel(okb, Bq[i].x, zz)); v[5] = B::as_f32(B::sel(okb, Bq[i].y, zz));
+        v[6] = B::as_f32(B::sel(okb, Bq[i].z, zz)); v[7] = B::as_f32(B::sel(okb, Bq[i].w, zz));
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) v[q8] = v[q8] * a.prescale;
+        u32 p0 = B::template pack<DT>(v[0], v[1]), p1 = B::template pack<DT>(v[2], v[3]);
+        u32 p2 = B::template pack<DT>(v[4], v[5]), p3 = B::template pack<DT>(v[6], v[7]);
+        o.x = B::sel(sw, p2, p0); o.y = B::sel(sw, p3, p1); o.z = B::sel(sw, p0, p2); o.w = B::sel(sw, p1, p3);
+      }
+      B::lds_w128(off, o, B::ptrue());
+      U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
+      B::lds_w128(off + GEO::PLANE, z, B::ptrue());
+    }
+  }
   static FFC_FN void k_rows_in(const KfArgs& a, int unit_id, Unit un) {
+    if (a.fast) { k_rows_in_fast(a, unit_id, un); return; }
     const i32 lane = B::opaque(B::lane());
 #pragma unroll
     for (int i = 0; i < BD::NCH; i++) {
