@@ -608,14 +608,16 @@ struct Body {
   template <bool NT>
   static FFC_FN void rows_dma_t(const ConvArgs& a, int h, int pq, Unit un) {
     const i32 lane = B::opaque(B::lane());
+    // Straight-line burst (round 4, late): no skip for rows beyond L or for the missing row of an odd batch -- they copy the clamped
+    // last element(s) of a valid row and rows_dma_finish zeroes them like any tail.  With a wave-uniform `continue` per row every
+    // copy sat in its own block, and in the prologue of the pair loop the compiler put a `s_waitcnt vmcnt(0)` in front of each
+    // one (ISA of bwd_kernel<.., ZM = 1>: `D W0` 32 times = 32 memory round trips in a row at the start of every head).
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
       const int b = 2 * pq + pl;
-      if (b >= a.B) continue;                                   // missing batch row: zero-filled by rows_dma_finish
-      const uint16_t* base = (const uint16_t*)a.u + row_off(b, true, a.sbu, h, a.L);
+      const uint16_t* base = (const uint16_t*)a.u + row_off(b < a.B ? b : a.B - 1, true, a.sbu, h, a.L);
 #pragma unroll
       for (int r = 0; r < GEO::N1 / 2; r++) {
-        if (r * GEO::Mi >= a.L) continue;                       // the whole row lies beyond L (wave-uniform)
         i32 n = B::imin(lane * 2 + (r * GEO::Mi + un.wq * 128), a.L - 2);      // clamped: the tail is zeroed after the wait
         B::template g2lds32<NT>(base, n >> 1, un.eb + pl * GEO::PLANE + (DMA_ROW0 + r) * (GEO::Mi * 2) + un.wq * 256);
       }
