@@ -429,6 +429,25 @@ struct Body {
   static FFC_FN void rows_load(const ConvArgs& a, int h, int pq, Unit un, RowRegsT<NC>& X) {
     const i32 lane = B::opaque(B::lane());
     const int fast = a.fast ? (a.stream ? 2 : 1) : 0;     // 2: streaming (non-temporal) fast path
+    if constexpr (!GEO::OUTER) {
+      // single-tile sizes: the 16-byte / element-wise decision once for the whole tile (round 4, late).  Inside gload8_rows it put each
+      // of the tile's four loads into a flow block whose merge with the element-wise arm carries a `s_waitcnt vmcnt(0)`: `L W0` four
+      // times, one request per memory round trip and wave -- 16 KB in flight per CU where the memory system wants ~48 (the short
+      // sequences sat at 2.6 - 3.4 TB/s).  Same loads, same predicates; only the branch moved.
+      if (fast) {
+#pragma unroll
+        for (int ii = 0; ii < NC; ii++) {
+          i32 idx = lane + (ii + I0) * 64;
+          i32 row = idx / CPR, m = (idx % CPR) * 8;
+#pragma unroll
+          for (int pl = 0; pl < 2; pl++) {
+            i32 b = (row + pq * GEO::G) * 2 + pl;
+            X.v[ii][pl] = gload8_rows((const uint16_t*)a.u, b, h, a, a.sbu, m, 1, b < a.B);
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int ii = 0; ii < NC; ii++) {
       const int i = ii + I0;
