@@ -8,6 +8,9 @@
 // Pair packing keeps working for dk: with z_u = u_a + i u_b and z_d = d_a + i d_b,
 //   Re iFFT( Z_d * conj(Z_u) ) = corr(d_a,u_a) + corr(d_b,u_b).
 #pragma once
+#ifndef FFC_KF_LATE
+#define FFC_KF_LATE 0
+#endif
 #include "ffc_body.h"
 
 namespace ffc {
@@ -766,10 +769,14 @@ struct Modes : Body<B, GEO, DT> {
       typename BD::KfRegs zv;
       z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
       typename BD::KfRegs kf;
-      if constexpr (WITH_DX) BD::load_kf(a, h, tau, kf);
+      // FFC_KF_LATE=1 (build switch, OFF; prepared for round 5, not measured): the k_f tile requested BEHIND the transform instead of next
+      // to the spectrum tile -- four load tuples instead of eight live across tile_fwd, where the allocator copies them out of the way of
+      // the MFMA operands and waits for them.
+      if constexpr (WITH_DX && FFC_KF_LATE == 0) BD::load_kf(a, h, tau, kf);
       A16 re, im;
       if (WREG >= GEO::TPW || tt < WREG) {
         BD::template tile_fwd<false>(tau, R, un, re, im);
+        if constexpr (WITH_DX && FFC_KF_LATE != 0) BD::load_kf(a, h, tau, kf);
         switch (tt) {
           case 0: if constexpr (WREG > 0) w_acc_tile<0>(zv, re, im); break;
           case 1: if constexpr (WREG > 1) w_acc_tile<1>(zv, re, im); break;
@@ -780,6 +787,7 @@ struct Modes : Body<B, GEO, DT> {
         WOld wold;
         w_load_old(slab, tau, first, wold);
         BD::template tile_fwd<false>(tau, R, un, re, im);
+        if constexpr (WITH_DX && FFC_KF_LATE != 0) BD::load_kf(a, h, tau, kf);
         w_update(slab, tau, wold, zv, re, im);
       }
       if constexpr (WITH_DX) {
