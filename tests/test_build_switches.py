@@ -1,0 +1,65 @@
+"""The build switches that select between two forms of the same arithmetic must not change a single bit (round 4's load-scheduling work:
+FFC_GATE_BATCH = 0 is the one-load-at-a-time form of the gated rows, FFC_RP_HOIST = 0 the multi-pass rows with the access-width switch
+inside every load, FFC_KF_LATE = 1 the prepared backward variant).  One simulator build with every switch flipped, compared with the
+default simulator on forward, backward and the spectrum-saving pair of single-tile, fused and multi-pass sizes, gated and ragged."""
+import ctypes, hashlib, os, subprocess, sys
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(os.path.dirname(HERE), "flash-fft-conv_amd")
+ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1"]
+
+
+def _alt_sim():
+    """built in-tree under lib/variants/sim_alt/ and reused while no source is newer"""
+    d = os.path.join(PKG, "lib", "variants", "sim_alt")
+    so = os.path.join(d, "libffcsim.so")
+    csrc = os.path.join(PKG, "csrc")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+    if not os.path.exists(so) or os.path.getmtime(so) < newest:
+        os.makedirs(d, exist_ok=True)
+        subprocess.check_call(["g++", "-O0", "-std=c++17", "-fPIC", "-shared", "-pthread"] + ALT_FLAGS + ["-o", so,
+                               os.path.join(csrc, "ffc_sim.cpp"), os.path.join(csrc, "ffc_plan.cpp")])
+    return so
+
+
+CASES = [(256, 200, 5, 2, 1, True), (1024, 1024, 3, 2, 0, True), (2048, 1024, 4, 1, 0, True), (4096, 2048, 5, 1, 1, True),
+         (32768, 16384, 3, 1, 0, False), (32768, 9000, 2, 1, 0, True), (65536, 32768, 3, 1, 0, True), (65536, 40004, 1, 1, 1, False)]
+_SCRIPT = r'''
+import sys, hashlib, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import simlib as S
+dig = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:12]
+for (N, L, B, H, dt, gated) in %r:
+    rng = np.random.default_rng(N + L)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None; post = S.to_bits(g2, dt) if gated else None
+    out = [dig(kf), dig(S.sim_conv_fwd(N, dt, S.to_bits(u, dt), kf, pre, post))]
+    du, dpre, dk = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, L, pre, post, 1)
+    out += [dig(du), dig(dk)] + ([dig(dpre)] if gated else [])
+    out += [dig(x) for x in S.sim_fwd_bwd_z(N, dt, S.to_bits(u, dt), S.to_bits(d, dt), kf, pre, post) if x is not None]
+    print(N, L, B, H, dt, gated, " ".join(out), flush=True)
+'''
+
+
+def _digests(sim_lib):
+    env = dict(os.environ)
+    if sim_lib:
+        env["FFC_SIM_LIB"] = sim_lib
+    else:
+        env.pop("FFC_SIM_LIB", None)
+    src = _SCRIPT % (HERE, PKG, os.path.dirname(HERE), CASES)
+    r = subprocess.run([sys.executable, "-c", src], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout.strip().splitlines()
+
+
+def test_build_switches_do_not_change_a_bit():
+    base = _digests(None)
+    alt = _digests(_alt_sim())
+    assert len(base) == len(CASES) == len(alt)
+    for a, b in zip(base, alt):
+        assert a == b, (a, b)
