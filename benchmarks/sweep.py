@@ -174,6 +174,15 @@ def sweep_rows(lg_lo=10, lg_hi=20):
         torch.cuda.empty_cache()
 
 
+def sweep_gated_rows(lgs=(10, 12, 14, 16)):
+    """gated, padded (fft = 2L) fwd + bwd at B=16 H=768: the reference's benchmark grid has these forms next to the plain ones
+    (benchmarks/benchmark_flashfftconv.py:150-212); a subset of the lengths keeps the default bench run short"""
+    for lg in lgs:
+        L = 1 << lg
+        yield conv_row(f"gated sweep L={L}", 2 * L, 16, 768, L, gated=True)
+        torch.cuda.empty_cache()
+
+
 # The reference's published table (README.md:224-230, BASELINE.md section 1): gated forward, fp16, L = N, time scaled to
 # B = 64 x H = 768 rows, 1 x H100-SXM.  Same shapes here (B, H shrunk as the reference's set_B_H does and rescaled the same
 # way, benchmarks/benchmark_flashfftconv.py:28-59, :111), same training-mode forward.
@@ -203,11 +212,24 @@ def readme_rows(sizes=None):
             mod.train()
         adj = 64 * 768 / (B * H)
         dout = torch.randn(B, H, N, device="cuda").to(torch.float16)
+        # the gated backward at the same shape (reference benchmarks/benchmark_flashfftconv.py:150-212 times fwd, bwd and memory
+        # of the gated forms; its README publishes the forward only)
+        y = mod(u, k, *g)
+        leaves = [u, k] + g
+
+        def bwd():
+            for t_ in leaves:
+                t_.grad = None
+            y.backward(dout, retain_graph=True)
+        (tb, _) = ev_time(bwd, set_iters(N))
+        del y
+        for t_ in leaves:
+            t_.grad = None
         pm = peak_mem_row(mod, u, k, g, dout, N)
         del dout
         yield {"row": f"README table N={N}", "peak_mem_bytes": pm, "fft": N, "L": N, "dtype": "float16", "gated": True, "B_run": B, "H_run": H,
                "fwd_ms_scaled_to_B64_H768": round(t * adj, 3), "fwd_ms_min_scaled": round(tmin * adj, 3),
-               "fwd_no_grad_ms_scaled": round(ti * adj, 3),
+               "fwd_no_grad_ms_scaled": round(ti * adj, 3), "bwd_ms_scaled": round(tb * adj, 3),
                "h100_ms_published": H100_GATED_FWD_MS[N], "speedup_vs_h100_published": round(H100_GATED_FWD_MS[N] / (t * adj), 2)}
         del u, k, g
         torch.cuda.empty_cache()
@@ -225,6 +247,9 @@ if __name__ == "__main__":
             print(json.dumps(r), flush=True)
     if which in ("all", "sweep"):
         for r in sweep_rows():
+            print(json.dumps(r), flush=True)
+    if which in ("all", "gated"):
+        for r in sweep_gated_rows():
             print(json.dumps(r), flush=True)
     if which in ("all", "readme"):
         for r in readme_rows():

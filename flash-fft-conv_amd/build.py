@@ -36,9 +36,18 @@ def check_agpr(asm_path):
     def close():
         # every accumulator is zeroed + updated (2 writes) and read for the update + the final store (2 reads), in the kernels
         # with the dk tail (Modes::dk_tail) once more for it (3 reads); any other count is a compiler spill into the same register
+        # the third read is only legitimate where the tail is instantiated: bwd_kernel<Geo<..>, ...> with more than one wave per
+        # unit (everything but Geo<16,16,16> = fft 4096); in any other kernel a third read IS the spill this audit exists for,
+        # and within one kernel all registers must agree
+        tail_ok = kernel is not None and kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi") \
+            and not kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi16ELi16ELi16EEE")
+        counts = set()
         for idx in set(reads) | set(writes):
-            if reads[idx] not in (2, 3) or writes[idx] != 2:
+            counts.add(reads[idx])
+            if reads[idx] not in ((2, 3) if tail_ok else (2,)) or writes[idx] != 2:
                 bad.append(f"{kernel}: a{idx} read {reads[idx]}x written {writes[idx]}x")
+        if len(counts) > 1:
+            bad.append(f"{kernel}: accumulation registers read unevenly ({sorted(counts)} reads)")
         reads.clear(); writes.clear()
 
     with open(asm_path) as fh:

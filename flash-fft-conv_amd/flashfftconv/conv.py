@@ -129,6 +129,7 @@ def reload_env():
     """tuning scripts: re-read FFC_* environment knobs into every cached plan (launches never read the environment)"""
     for p in list(_PLANS.values()):
         _lib.lib().ffc_plan_reload_env(p.handle)
+        p.__dict__.pop("_ws_cache", None)      # the workspace size depends on FFC_WG_MULT (chunks per head): ADVICE r04
 
 
 # Buffers the REFERENCE module registers (persistent, so they are in every checkpoint saved from it):
@@ -196,6 +197,11 @@ def _spectrum_budget_ok(nbytes, device, mode=True):
     return True
 
 
+# how often a training forward wanted to keep spectra and took the recomputing path instead (budget or allocation failure):
+# benchmarks and tests assert on it so that a silent switch of kernels cannot hide in a timing
+SPECTRUM_FALLBACKS = {"budget": 0, "oom": 0}
+
+
 def _spectrum_buffer(plan, B, H, device, gated=True, mode=True):
     """Buffer for the spectra FFT(u * pregate) that the forward pass keeps for the backward pass (ffc_conv_fwd_z / ffc_conv_bwd_z),
     or None: no memory for it (the caller then takes the recomputing path, like the reference).  Every fused plan has the path:
@@ -205,11 +211,15 @@ def _spectrum_buffer(plan, B, H, device, gated=True, mode=True):
     if plan.seqlen <= 1024 and not gated:
         return None
     n = _lib.lib().ffc_spectrum_bytes(plan.handle, B, H)
-    if n <= 0 or not _spectrum_budget_ok(n, device, mode):
+    if n <= 0:
+        return None
+    if not _spectrum_budget_ok(n, device, mode):
+        SPECTRUM_FALLBACKS["budget"] += 1
         return None
     try:
         return torch.empty(n, dtype=torch.uint8, device=device)
     except torch.cuda.OutOfMemoryError:
+        SPECTRUM_FALLBACKS["oom"] += 1
         return None
 
 
@@ -321,7 +331,8 @@ class _TorchOps:
         plan = self._plan(M)
         Bp, hp, _ = x.shape
         kf = torch.empty(hp, plan.kf_elems, 2, dtype=dt, device=self.device)
-        z = _spectrum_buffer(plan, Bp, hp, self.device, True, self.mod.save_spectrum) if keep else None
+        # (the module-level budget test of the HBM-level path already charged x + z + y: no second charge here)
+        z = _spectrum_buffer(plan, Bp, hp, self.device, True, "always") if keep else None
         y = torch.empty_like(x)
         _lib.check(_lib.lib().ffc_conv_fwd_kx(plan.handle, _lib.ptr(xk), ctypes.c_float(scale), _lib.ptr(kf), _lib.ptr(x), _lib.ptr(y),
                                               _lib.ptr(z), Bp, hp, M, _lib.stream_ptr()), "ffc_conv_fwd_kx")
@@ -342,7 +353,7 @@ class _TorchOps:
     def conv_save(self, dt, M, x, kf):
         """inner forward that also keeps the inner spectra (None when the inner plan has no such path)"""
         plan = self._plan(M)
-        z = _spectrum_buffer(plan, x.shape[0], x.shape[1], self.device, True, self.mod.save_spectrum)
+        z = _spectrum_buffer(plan, x.shape[0], x.shape[1], self.device, True, "always")      # charged once, at module level
         return (_conv(plan, x, kf, None, None, False), None) if z is None else (_conv_save(plan, x, kf, None, None, z), z)
 
     def bwd(self, dt, M, xd, xu, kf, z=None):
@@ -534,6 +545,8 @@ class _FlashFFTConvFn(torch.autograd.Function):
             keep = mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
             if keep:      # kept: inner-size rows x (4 B per point and pair), their spectra z (4 B), gated also the inner output y (4 B)
                 keep = _spectrum_budget_ok(((u.shape[0] + 1) // 2) * u.shape[1] * mod.seqlen * (12 if ctx.gated else 8), u.device, mod.save_spectrum)
+                if not keep:
+                    SPECTRUM_FALLBACKS["budget"] += 1
             # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
             ctx.fac = fac = _big.choose(mod.seqlen, max(u.shape[-1], k.shape[-1]), _TorchOps)
             try:
@@ -541,6 +554,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             except torch.cuda.OutOfMemoryError:
                 if not keep:
                     raise
+                SPECTRUM_FALLBACKS["oom"] += 1
                 out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False, None, fac)
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)

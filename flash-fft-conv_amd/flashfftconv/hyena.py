@@ -110,7 +110,7 @@ def gated_conv_from_slices(conv, uc, k):
     # (the strided launchers address one tensor with 31-bit element offsets: (B-1) * 3*D*L + D*L has to stay below 2^31,
     # where the composition on contiguous copies only needs B*D*L < 2^31)
     too_wide = (uc.shape[0] - 1) * 3 * D * L + D * L >= 2 ** 31
-    if conv._big or conv._kf_keep is not None or (D * L) % 8 or not uc.is_contiguous() or too_wide:
+    if conv._big or conv._route_big(max(L, k.shape[-1])) or conv._kf_keep is not None or (D * L) % 8 or not uc.is_contiguous() or too_wide:
         x1, x2, v = (t.contiguous() for t in uc.split(D, dim=1))
         return conv(v, k, x1, x2)
     _check_inputs(conv, uc[:, :D], k, ())

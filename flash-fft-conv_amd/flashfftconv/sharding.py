@@ -52,10 +52,12 @@ _CAPS = {}
 
 
 def _caps(group, like):
-    key = (id(group) if group is not None else None, like.device.type)
+    # keyed by the backend + the group's ranks, not id(group): a destroyed group's id can be handed to a new one
+    backend = dist.get_backend(group)
+    key = (backend, tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)), like.device.type)
     c = _CAPS.get(key)
     if c is None:
-        if dist.get_backend(group) == "nccl":          # RCCL: both tensor collectives
+        if backend == "nccl" and like.device.type == "cuda":          # RCCL on device tensors: both tensor collectives
             c = (True, True)
         else:
             world = dist.get_world_size(group)
@@ -531,7 +533,8 @@ class BatchShardedFFTConv(torch.nn.Module):
             return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
         if self._ops is not None:
             ops = self._ops
-        elif self.conv._big:
+        elif self.conv._big or self.conv._route_big(max(u.shape[-1], k.shape[-1])):
+            # (fft 131072 with rows longer than N/2 takes the HBM-level form in the single-rank module: the same route here)
             ops = _BigOps(self.conv, u.device, max(u.shape[-1], k.shape[-1]))
         else:
             ops = _HipOps(self.conv, u.device)

