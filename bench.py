@@ -421,12 +421,12 @@ def main():
     # the backward kernel on saved spectra executes one forward half + one inverse half per pair
     mf_bwd_saved = mf_bwd - 32 * (4 + 16)
     roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF,ZM=1> on saved spectra: du + dk in one launch (dk_f stays in the accumulation registers and is inverted by the same workgroup; the recomputing form is the ZM=0 instantiation)", mf_bwd_saved, dense_bwd, bwd_bytes,
-                    kt_step["conv_bwd_k"], prof_traffic("r04_pmc_bwd_kernel.txt", "traffic") or prof_traffic("r03_pmc_bwd_kernel.txt", "traffic"))
+                    kt_step["conv_bwd_k"], prof_traffic("r05_pmc_bwd_kernel.txt", "traffic") or prof_traffic("r04_pmc_bwd_kernel.txt", "traffic"))
     roof_bwd["launch_ms_isolated_loop"] = kt["conv_bwd_k"] * 1e3
     roof_bwd["launch_ms_without_dk_tail"] = kt_step["bwd_fused_saved"] * 1e3      # + dk_ifft as its own launch (round 3 form)
     roof_bwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_read": npair * N * 4, "u_not_read_any_more": -B * H * L * 2}
     roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> (training forward: k -> k_f of the head, convolution, stores the spectra)", mf_fwd, dense_fwd, fwd_bytes,
-                    kt_step["conv_fwd_k"], prof_traffic("r04_pmc_conv_kernel.txt", "traffic") or prof_traffic("r03_pmc_conv_kernel.txt", "traffic"))
+                    kt_step["conv_fwd_k"], prof_traffic("r05_pmc_conv_kernel.txt", "traffic") or prof_traffic("r04_pmc_conv_kernel.txt", "traffic"))
     roof_fwd["launch_ms_isolated_loop"] = kt["conv_fwd_k"] * 1e3
     roof_fwd["launch_ms_without_kfft_head"] = kt_step["conv_fwd_save"] * 1e3      # + kfft as its own launch (round 3 form)
     roof_fwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_write": npair * N * 4}

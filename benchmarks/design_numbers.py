@@ -1,12 +1,13 @@
-"""Renders the measured block of DESIGN.md section 4.0 and the README numbers line from profiles/r04_bench.json (one bench.py run)."""
+"""Renders the measured block of DESIGN.md section 4 and the README numbers line from profiles/r05_bench_full.json (the complete object of one
+bench.py run, written next to the contract line) -- argv[1] overrides the path.  Round-4 columns come from profiles/r04_bench.json."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])
+d = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_bench_full.json")))
 k, pm = d["kernel_ms"], d["peak_mem_bytes"]
 rf, rb = d["roofline_fwd"], d["roofline"]
 out = []
 out.append(f"Config 2 (B16 H768 L16384, fft 32768, bf16): **{d['ms_per_step']:.3f} ms per fwd+bwd step = {d['value']/1e6:.2f} M seq/s** "
-           f"(round 3, driver: 1.265); the same step with `save_spectrum = False`: {d['recompute']['ms_per_step']:.2f} ms; under "
+           f"(round 4: 1.19 on the builder's box, no driver record; round 3, driver: 1.265); the same step with `save_spectrum = False`: {d['recompute']['ms_per_step']:.2f} ms; under "
            f"`torch.utils.benchmark.Timer` (the reference's tool): {d['ms_per_step_torch_benchmark_timer']:.2f} ms.  CPU torch.fft oracle on the box's host: "
            f"{d['cpu_baseline']['value']/1e3:.1f} K seq/s at the best of six thread counts ({d['cpu_baseline']['cores']}).  Measured peaks: stream copy "
            f"{d['peak_measured']['stream_copy_GBs']/1e3:.2f} TB/s (2 GiB, streaming; the guide's figure is 6.29), dense bf16 MFMA {d['peak_measured']['mfma_bf16_dense_TFLOPs']/1e3:.2f} PFLOP/s.")
@@ -15,7 +16,7 @@ out.append("| launch (config 2) | ms inside the step | isolated loop | fractions
 out.append("|---|---|---|---|")
 iso = d["kernel_ms_isolated_loops"]
 out.append(f"| `ffc_conv_fwd_k`: conv_kernel<32,32,32,bf16,HALF,SZ> incl. k → k_f of the head, stores the spectra | **{k['conv_fwd_k']:.3f}** | {iso['conv_fwd_k']:.3f} | {rf['frac_hbm']:.3f} HBM / {rf['frac_executed']:.3f} MFMA |")
-out.append(f"| `ffc_conv_bwd_k`: bwd_kernel<32,32,32,bf16,HALF,ZM=1> incl. the dk tail — dominant | **{k['conv_bwd_k']:.3f}** | {iso['conv_bwd_k']:.3f} | **{rb['frac_hbm']:.3f} HBM** / {rb['frac_executed']:.3f} MFMA; PMC traffic {rb['traffic']/1e6:.0f} MB (kernel without the tail) |")
+out.append(f"| `ffc_conv_bwd_k`: bwd_kernel<32,32,32,bf16,HALF,ZM=1> incl. the dk tail — dominant | **{k['conv_bwd_k']:.3f}** | {iso['conv_bwd_k']:.3f} | **{rb['frac_hbm']:.3f} HBM** / {rb['frac_executed']:.3f} MFMA; PMC traffic {(rb['traffic'] or 0)/1e6:.0f} MB |")
 out.append(f"| the same work as round 3's four launches: kfft / conv_fwd_save / bwd_fused_saved / dk_ifft | {k['kfft']:.3f} / {k['conv_fwd_save']:.3f} / {k['bwd_fused_saved']:.3f} / {k['dk_ifft']:.3f} (sum {d['kernel_sum_check']['four_launch_form_in_step_ms']:.3f}) | | two-launch sum {d['kernel_sum_check']['sum_event_bracketed_in_step_ms']:.3f} |")
 out.append("")
 mb = lambda v: f"{v/1e6:.0f}" if isinstance(v, (int, float)) else "-"
@@ -25,16 +26,16 @@ out.append(f"Peak memory of config 2 above the resident inputs ({mb(pm['inputs_b
            f"(forward / fwd+bwd): **{pm['saving_vs_torch_fft_fwd']}× / {pm['saving_vs_torch_fft_fwd_bwd']}× less** than torch.fft (reference README.md:232 publishes 6.65× … 2.81×); "
            f"every row of `configs`, `sweep` and `readme_table` carries the same object.")
 out.append("")
-out.append("| row (module level incl. k → k_f and dk; forward = the TRAINING forward; median of 3 × 20) | fwd / bwd ms | alg. HBM fraction fwd / bwd | round 3 (profiles/r03_bench.json) | peak fwd+bwd MB (saved / recompute / torch.fft) |")
+out.append("| row (module level incl. k → k_f and dk; forward = the TRAINING forward; median of 3 × 20) | fwd / bwd ms | alg. HBM fraction fwd / bwd | round 4 (profiles/r04_bench.json, builder's run) | peak fwd+bwd MB (saved / recompute / torch.fft) |")
 out.append("|---|---|---|---|---|")
 r3 = {}
 try:
-    b3 = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench.json")).read().strip().splitlines()[-1])      # the builder's round-3 run
+    b3 = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench.json")).read().strip().splitlines()[-1])      # the builder's round-4 run
     for r in b3.get("configs", []) + b3.get("sweep", []):
         r3[r["row"]] = (r.get("fwd_ms"), r.get("bwd_ms"))
 except Exception:
     pass
-for r in d["configs"] + d["sweep"]:
+for r in d["configs"] + d["sweep"] + d.get("sweep_gated", []):
     p = r.get("peak_mem_bytes") or {}
     old = r3.get(r["row"])
     out.append(f"| {r['row']}{'*' if r.get('rescaled') else ''} | {r['fwd_ms']:.4g} / **{r['bwd_ms']:.4g}** | {r['fwd_hbm_frac']:.3f} / {r['bwd_hbm_frac']:.3f} | "
@@ -47,14 +48,15 @@ out.append("The reference's published table (README.md:224-230: gated forward, f
            + " / ".join(str(r["fft"]) for r in t) + ": " + " / ".join(f"{r['fwd_ms_scaled_to_B64_H768']:.3g}" for r in t) + " ms against the published "
            + " / ".join(f"{r['h100_ms_published']:.3g}" for r in t) + f" — **{min(r['speedup_vs_h100_published'] for r in t):.1f}–{max(r['speedup_vs_h100_published'] for r in t):.1f}×** row by row "
            "(other hardware: `vs_baseline` stays null); memory against torch.fft for the same forward: "
-           + " / ".join(f"{r['peak_mem_bytes'].get('saving_vs_torch_fft_fwd', '-')}×" for r in t) + ".")
+           + " / ".join(f"{r['peak_mem_bytes'].get('saving_vs_torch_fft_fwd', '-')}×" for r in t) + ".  The gated BACKWARD at the same shapes (scaled the same way; the reference publishes no backward column): "
+           + " / ".join(f"{r.get('bwd_ms_scaled', 0):.3g}" for r in t) + " ms.")
 block = "\n".join(out)
-readme = (f"**{d['ms_per_step']:.2f} ms per fwd+bwd step at B=16, H=768, L=16384, fft 32768 = {d['value']/1e6:.1f} M seq/s** (round 3: 1.265 ms; recompute mode "
+readme = (f"**{d['ms_per_step']:.2f} ms per fwd+bwd step at B=16, H=768, L=16384, fft 32768 = {d['value']/1e6:.1f} M seq/s** (round 4: 1.19; round 3, driver: 1.265 ms; recompute mode "
           f"{d['recompute']['ms_per_step']:.2f}); the step is two launches now: forward incl. k → k_f {k['conv_fwd_k']:.2f} ms, backward incl. dk {k['conv_bwd_k']:.2f} ms = "
           f"{rb['frac_hbm']:.2f} of the HBM roofline; peak memory {mb(pm['fwd_bwd_save_spectrum'])} MB (recompute {mb(pm['fwd_bwd_recompute'])} MB, torch.fft {mb(pm['fwd_bwd_torch_fft'])} MB); "
           f"config 3 {d['configs'][1]['fwd_ms']:.2f} / {d['configs'][1]['bwd_ms']:.2f} ms; config 4 (4M, L = 1M) {d['configs'][2]['fwd_ms']:.2f} / {d['configs'][2]['bwd_ms']:.2f} ms; the reference's published H100 table "
           f"(gated fp16 forward) beaten {min(r['speedup_vs_h100_published'] for r in t):.1f}–{max(r['speedup_vs_h100_published'] for r in t):.1f}× row by row; conv1d k=3 at {d['configs'][3].get('fwd_GBs', 0)/1e3:.1f} TB/s; see `DESIGN.md` §4 and `profiles/`.")
-for path, key, val in ((os.path.join(ROOT, "DESIGN.md"), "@@R4BLOCK@@", block), (os.path.join(ROOT, "README.md"), "@@README_NUMBERS@@", readme)):
+for path, key, val in ((os.path.join(ROOT, "DESIGN.md"), "@@R5BLOCK@@", block), (os.path.join(ROOT, "README.md"), "@@README_NUMBERS@@", readme)):
     s = open(path).read()
     a, b = f"<!-- {key.strip('@')} -->", f"<!-- /{key.strip('@')} -->"
     if key in s:

@@ -39,8 +39,9 @@ def check_agpr(asm_path):
         # the third read is only legitimate where the tail is instantiated: bwd_kernel<Geo<..>, ...> with more than one wave per
         # unit (everything but Geo<16,16,16> = fft 4096); in any other kernel a third read IS the spill this audit exists for,
         # and within one kernel all registers must agree
-        tail_ok = kernel is not None and kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi") \
-            and not kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi16ELi16ELi16EEE")
+        tail_ok = kernel is not None and ((kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi")
+                                           and not kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi16ELi16ELi16EEE"))
+                                          or kernel.startswith("_Z13bwd_rp_kernelIN3ffc3GeoILi32ELi32ELi32EEELi0E"))   # bf16 multi-pass: dk_tail_rp
         counts = set()
         for idx in set(reads) | set(writes):
             counts.add(reads[idx])

@@ -203,7 +203,7 @@ struct Body {
   // are stepped by w^2 and w^8 (two elements per packed instruction).
   using F2 = typename B::F2;
   static FFC_FN void chain8p(i32 base, i32 step, float sign, float scale, F2 (&tr)[4], F2 (&ti)[4],
-                             int nmask = GEO::N - 1, float inv_n = 1.0f / (float)GEO::N) {
+                             int nmask = GEO::N - 1, float inv_n = 1.0f / (float)GEO::N, f32* w8c = nullptr, f32* w8s = nullptr) {
     f32 c0, s0, c1, s1, c8, s8;
     cis_rev(base, sign, &c0, &s0, nmask, inv_n);
     cis_rev(step, sign, &c1, &s1, nmask, inv_n);
@@ -215,6 +215,7 @@ struct Body {
     B::cmulp(tr[0], ti[0], c2, s2, tr[1], ti[1]);
     B::cmulp(tr[0], ti[0], c8, s8, tr[2], ti[2]);
     B::cmulp(tr[1], ti[1], c8, s8, tr[3], ti[3]);
+    if (w8c) { *w8c = c8; *w8s = s8; }
   }
   // apply a chain8p result to accumulator rows 8*half + {0..7}
   static FFC_FN void apply8(A16& re, A16& im, int half, const F2 (&tr)[4], const F2 (&ti)[4]) {
@@ -223,6 +224,40 @@ struct Body {
 #endif
 #pragma unroll
     for (int i = 0; i < 4; i++) B::template cmul2v<false>(re, im, 8 * half + 2 * i, tr[i], ti[i]);
+  }
+  // Round 5: both accumulator halves of a tile from ONE chain when they share the step (rows off and off + 16 of the same
+  // twiddle column: 32-point outer digit in phases A, 32-point last inner digit in the inverse twiddle).  The second half is the
+  // first one times w^16 = (w^8)^2 -- four packed complex multiplies instead of a second chain with its three v_sin / v_cos pairs,
+  // their argument preparation and the wait states behind them (6 -> 3 transcendental pairs per tile).
+  // FFC_CHAIN16=0: two chains, the round-4 form (A/B builds).
+#ifndef FFC_CHAIN16
+#define FFC_CHAIN16 1
+#endif
+  // phases A: 32-point outer digit; not in the 128-VGPR kernels of fft 8192 (Geo<32,16,16> on a LEAN_OUTER backend: with the chain's
+  // w^8 kept for the second half the allocator parked values in a0..a3 -- build.py check_agpr)
+  static constexpr bool CHAIN16_A = GEO::N1 == 32 && (!B::LEAN_OUTER || GEO::N2 == 32);
+  // the per-tile outer stage (128-VGPR kernels, full-length rows) keeps two chains: with one, the recomputing full-length backward of
+  // fft 32768 spilled one value into a0 (build.py check_agpr)
+#ifndef FFC_CHAIN16_TILE
+#define FFC_CHAIN16_TILE 0
+#endif
+  static FFC_FN void twiddle16(A16& re, A16& im, i32 base, i32 step, float sign, float scale,
+                               int nmask = GEO::N - 1, float inv_n = 1.0f / (float)GEO::N) {
+    F2 tr[4], ti[4];
+    if constexpr (FFC_CHAIN16 != 0) {
+      f32 c8, s8;
+      chain8p(base, step, sign, scale, tr, ti, nmask, inv_n, &c8, &s8);
+      apply8(re, im, 0, tr, ti);
+      const f32 c16 = c8 * c8 - s8 * s8, s16 = (c8 + c8) * s8;
+#pragma unroll
+      for (int i = 0; i < 4; i++) B::cmulp(tr[i], ti[i], c16, s16, tr[i], ti[i]);
+      apply8(re, im, 1, tr, ti);
+    } else {
+      chain8p(base, step, sign, scale, tr, ti, nmask, inv_n);
+      apply8(re, im, 0, tr, ti);
+      chain8p(base + 16 * step, step, sign, scale, tr, ti, nmask, inv_n);
+      apply8(re, im, 1, tr, ti);
+    }
   }
   // dtype pair (x) dtype pair, rounded back to dtype (the reference multiplies gates in the
   // activation dtype: kernels_bf16/monarch_cuda_32_32_32_kernel_bf16.h:409-429, 613-634).
@@ -382,7 +417,9 @@ struct Body {
 #if defined(FFC_KO) && (FFC_KO & 2)
     { U4 z; z.x = B::as_u32(B::i2f(n)); z.y = z.x; z.z = z.x; z.w = z.x; return z; }     // knock-out experiment: no row loads
 #endif
-    if (fast) return (STREAM_ROWS && fast == 2) ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
+    // B::FAST_ONLY: kernel instantiations that are only launched on 16-byte-aligned tensors with L % 8 == 0 (the element-wise arm is
+    // compiled out: with both arms in one kernel every load sits in its own flow block with a `s_waitcnt vmcnt(0)` at the merge)
+    if (B::FAST_ONLY || fast) return (STREAM_ROWS && fast == 2) ? B::g_r128_nt(base, B::imin(n, L - 8) >> 3) : B::g_r128(base, B::imin(n, L - 8) >> 3);
     u32 w[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -397,7 +434,7 @@ struct Body {
 #if defined(FFC_KO) && (FFC_KO & 2)
     if (B::as_f32(v.x) != B::as_f32(v.x) + 1.0f) return;      // knock-out experiment: (practically) never stores
 #endif
-    if (fast) {
+    if (B::FAST_ONLY || fast) {
       if (STREAM_ROWS && fast == 2) B::g_w128_nt(base, n >> 3, v, (n < L) && rowok);
       else B::g_w128(base, n >> 3, v, (n < L) && rowok);
       return;
@@ -836,8 +873,24 @@ struct Body {
 #ifndef FFC_RP_HOIST
 #define FFC_RP_HOIST 1
 #endif
+// chunks per batch of the multi-pass row functions in the fast-only BACKWARD kernels (128-VGPR budget; the forward kernels take 4)
+#ifndef FFC_RP_BATCH_LEAN
+#define FFC_RP_BATCH_LEAN 2
+#endif
+// 0: the multi-pass backward always runs the kernel with the run-time access-width switch (A/B builds, bit-identity test)
+#ifndef FFC_RP_FASTK
+#define FFC_RP_FASTK 1
+#endif
   template <int NC>
   static FFC_FN void rows_in_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    if constexpr (B::FAST_ONLY) {
+      // round 5, multi-pass BACKWARD kernels (the 16-byte path as a kernel instantiation of its own, bwd_rp_kernel<.., FASTK = true>):
+      // rows that fit one block (L <= M: the padded case) are the single-pass row load -- sum_n0 has one term, the pass factor lives
+      // in the outer-digit matrix and the twiddle phase -- with every load of the wave's slice in flight; longer rows in batches
+      if (a.L <= GEO::N) { rows_in<NC>(a, h, pq, un); return; }
+      rows_in_rp_t<NC, true>(a, h, pq, un, ps);
+      return;
+    }
     if constexpr (FFC_RP_HOIST != 0 && !B::LEAN_OUTER) {
       if (a.fast) { rows_in_rp_t<NC, true>(a, h, pq, un, ps); return; }
     }
@@ -845,7 +898,8 @@ struct Body {
   }
   template <int NC, bool FASTP>
   static FFC_FN void rows_in_rp_t(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
-    constexpr int GB = NC < GB_RP ? NC : GB_RP;
+    constexpr int GB0 = (B::FAST_ONLY && B::LEAN_OUTER) ? FFC_RP_BATCH_LEAN : GB_RP;
+    constexpr int GB = NC < GB0 ? NC : GB0;
     static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
     const int fast = FASTP ? (a.stream ? 2 : 1) : (a.fast ? (a.stream ? 2 : 1) : 0);
@@ -939,6 +993,7 @@ struct Body {
   // (s,-r).  Passes k0 > 0 add to what the SAME wave stored in the earlier passes (its own column slice).
   template <int NC>
   static FFC_FN void rows_out_rp(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
+    if constexpr (B::FAST_ONLY) { rows_out_rp_t<NC, true>(a, h, pq, un, ps); return; }
     if constexpr (FFC_RP_HOIST != 0 && !B::LEAN_OUTER) {
       if (a.fast) { rows_out_rp_t<NC, true>(a, h, pq, un, ps); return; }
     }
@@ -948,7 +1003,8 @@ struct Body {
   static FFC_FN void rows_out_rp_t(const ConvArgs& a, int h, int pq, Unit un, Pass ps) {
     // batches of chunks: the earlier passes' sums (passes k0 > 0) and, on the last pass, the output gate of a batch are requested
     // together ahead of the work on them (round 4; before: the sums up front in the forward kernels only, the gate chunk by chunk)
-    constexpr int GB = B::LEAN_OUTER ? (NC < GB_RP ? NC : GB_RP) : (NC < 4 ? NC : 4);
+    constexpr int GBL = B::FAST_ONLY ? FFC_RP_BATCH_LEAN : GB_RP;
+    constexpr int GB = B::LEAN_OUTER ? (NC < GBL ? NC : GBL) : (NC < 4 ? NC : 4);
     static_assert(NC % GB == 0, "row batch");
     const i32 lane = B::opaque(B::lane());
     const int fast = FASTP ? (a.stream ? 2 : 1) : (a.fast ? (a.stream ? 2 : 1) : 0);
@@ -1066,6 +1122,12 @@ struct Body {
       cmm<!FWD, false>(re, im, op, F1, ms_lim);
       if (FWD) {
         // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
+        if constexpr (CHAIN16_A && FFC_CHAIN16_TILE) {              // both halves share the column m: one chain (twiddle16)
+          i32 m = j * 4 + (w * 128 * GEO::S1 + t);
+          i32 k0 = hi * 4;
+          if constexpr (RP) twiddle16(re, im, m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+          else twiddle16(re, im, m * k0, m, -1.0f, s_fwd);
+        } else
 #pragma unroll
         for (int half = 0; half < 2; half++) {     // accumulator registers 0-7 / 8-15 (rows +16)
           const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
@@ -1152,6 +1214,12 @@ struct Body {
         cmm<!FWD, false>(re, im, op, F1, ms_lim);
         if (FWD) {
           // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
+          if constexpr (CHAIN16_A) {              // both halves share the column m: one chain (twiddle16)
+            i32 m = j * 4 + (w * 128 * GEO::S1 + 2 * tp + th);
+            i32 k0 = hi * 4;
+            if constexpr (RP) twiddle16(re, im, m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+            else twiddle16(re, im, m * k0, m, -1.0f, s_fwd);
+          } else
 #pragma unroll
           for (int half = 0; half < 2; half++) {     // accumulator registers 0-7 / 8-15 (rows +16)
             const int s1 = (16 * half) / GEO::N1;     // second half: next column set when N1 == 16
@@ -1208,6 +1276,106 @@ struct Body {
     }
   }
 
+  // Round 5: all four column tiles of the wave in one pass (forward / dx kernels: 256-VGPR budget).  The tile-pair form reads and
+  // writes 4 bytes per lane at an 8-byte lane stride: `ds_read_b32` / `ds_write_b32` bank addresses are (a / 4) mod 32 over 32-lane
+  // groups (MI355X_MICROARCH.md, LDS), so lanes j and j + 16 meet on one bank -- every access of phases A / C was 2-way
+  // conflicted (PMC, round 4: bank-conflict cycles = 33 % of the LDS-active cycles).  Here a lane moves the whole 8-byte chunk
+  // (elements of tiles 0..3 of one row): `ds_read_b64` is conflict-free at that stride (32 lanes = one 256-byte bank row) and
+  // `ds_write_b64` covers 16 lanes x 8 bytes per group; half the LDS instructions, a quarter of the LDS-array cycles.  The first
+  // tile pair's results wait as packed row pairs (32 dwords) for the second pair's.  Same arithmetic as outer_stage_pair, so the
+  // results are bit-identical (simulator test).  FFC_OUTER_QUAD=0: the tile-pair form (A/B builds).
+#ifndef FFC_OUTER_QUAD
+#define FFC_OUTER_QUAD 1
+#endif
+  template <bool FWD, bool HALF, bool RP = false>
+  static FFC_FN void outer_stage_quad(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
+    const i32 lane = B::opaque(B::lane());
+    const int w = un.wq;
+    const i32 j = lane & 31, hi = lane >> 5;
+    constexpr int ms_lim = (FWD && HALF && GEO::N1 == 32) ? 1 : 2;
+    i32 colb[GEO::S1];
+#pragma unroll
+    for (int s = 0; s < GEO::S1; s++)
+      colb[s] = e_off<GEO, i32>(hi * 4, j * 4 + (s * 128 + w * 128 * GEO::S1)) + un.eb;
+    Mat F1;
+    if constexpr (RP) load_mat(F1, FWD ? ps.mat_fwd : ps.mat_inv, lane);
+    else lds_mat(F1, GEO::L_F1);
+    U2 rawr[2][8], rawi[2][8];
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++) {
+      if (ms >= ms_lim) continue;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int c = 16 * ms + 8 * (e >> 2) + (e & 3);
+        const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+        i32 off = colb[s1] + rwc * (GEO::Mi * 2);
+        if (FWD && HALF && row_dead(c)) { rawr[ms][e].x = B::uconst(0); rawr[ms][e].y = B::uconst(0); rawi[ms][e] = rawr[ms][e]; continue; }
+        rawr[ms][e] = B::lds_r64(off); rawi[ms][e] = B::lds_r64(off + GEO::PLANE);
+      }
+    }
+    u32 p0r[16], p0i[16];          // tiles (0, 1) of every result row, packed, until tiles (2, 3) are done
+#pragma unroll
+    for (int tp = 0; tp < 2; tp++) {
+      A16 re0, im0;
+#pragma unroll
+      for (int th = 0; th < 2; th++) {
+        Op op;
+#pragma unroll
+        for (int ms = 0; ms < 2; ms++) {
+          if (ms >= ms_lim) continue;
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const u32 ar = tp ? rawr[ms][2 * d].y : rawr[ms][2 * d].x, br = tp ? rawr[ms][2 * d + 1].y : rawr[ms][2 * d + 1].x;
+            const u32 ai = tp ? rawi[ms][2 * d].y : rawi[ms][2 * d].x, bi = tp ? rawi[ms][2 * d + 1].y : rawi[ms][2 * d + 1].x;
+            op.r[ms][d] = th ? B::merge_hi(ar, br) : B::merge_lo(ar, br);
+            op.i[ms][d] = th ? B::merge_hi(ai, bi) : B::merge_lo(ai, bi);
+          }
+        }
+        A16 re, im;
+        re = B::a16_zero(); im = B::a16_zero();
+        cmm<!FWD, false>(re, im, op, F1, ms_lim);
+        if (FWD) {
+          if constexpr (CHAIN16_A) {
+            i32 m = j * 4 + (w * 128 * GEO::S1 + 2 * tp + th);
+            i32 k0 = hi * 4;
+            if constexpr (RP) twiddle16(re, im, m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+            else twiddle16(re, im, m * k0, m, -1.0f, s_fwd);
+          } else
+#pragma unroll
+          for (int half = 0; half < 2; half++) {
+            const int s1 = (16 * half) / GEO::N1;
+            i32 m = j * 4 + (s1 * 128 + w * 128 * GEO::S1 + 2 * tp + th);
+            i32 k0 = hi * 4 + ((16 * half) % GEO::N1);
+            F2 tr[4], ti[4];
+            if constexpr (RP) chain8p(m * (k0 * ps.R + ps.k0), m * ps.R, -1.0f, s_fwd, tr, ti, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+            else chain8p(m * k0, m, -1.0f, s_fwd, tr, ti);
+            apply8(re, im, half, tr, ti);
+          }
+        }
+        if (th == 0) {
+          re0 = re; im0 = im;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (!FWD && HALF && row_dead((r & 3) + 8 * (r >> 2))) continue;   // rows beyond L: never stored
+            const u32 vr = B::template pack<DT>(re0[r], re[r]), vi = B::template pack<DT>(im0[r], im[r]);
+            if (tp == 0) {
+              p0r[r] = vr; p0i[r] = vi;
+            } else {
+              const int c = (r & 3) + 8 * (r >> 2);
+              const int s1 = c / GEO::N1, rwc = c % GEO::N1;
+              i32 off = colb[s1] + rwc * (GEO::Mi * 2);
+              U2 wr, wi;
+              wr.x = p0r[r]; wr.y = vr; wi.x = p0i[r]; wi.y = vi;
+              B::lds_w64(off, wr);
+              B::lds_w64(off + GEO::PLANE, wi);
+            }
+          }
+        }
+      }
+    }
+  }
+
   // The forward/dx kernels take the tile-pair variant (fastest); the backward kernels, which run on the
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
   template <bool FWD, bool HALF, bool RP = false, bool DIN = false>
@@ -1221,6 +1389,10 @@ struct Body {
 #endif
     // backward kernels (128-VGPR budget): the tile-pair form only fits with one K-step of raw rows (half-empty outer digit)
     if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF && GEO::N1 == 32))) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
+    // (HALF kernels only: same box, round 5 -- forward -1 ... -3 % at L <= N/2 (config 2 0.4474 -> 0.4334 ms with the chain change, gated
+    // fft 16384 -2.8 %), but the full-length spectrum-saving forward came out 5 % SLOWER with it (0.695 -> 0.730 ms, no spills: 28 more
+    // live registers through phase C), the full-length plain forward 1.5 % faster: profiles/r05_ab_kernels.txt)
+    else if constexpr (!B::LEAN_OUTER && FFC_OUTER_QUAD != 0 && HALF) outer_stage_quad<FWD, HALF, RP>(L, un, s_fwd, ps);
     else outer_stage_pair<FWD, HALF, RP>(L, un, s_fwd, ps);
   }
 
@@ -1388,6 +1560,16 @@ struct Body {
           f32 xr = re[r], xi = im[r];
           re[r] = xr * tr - xi * ti;
           im[r] = xr * ti + xi * tr;
+        }
+      } else if constexpr (GEO::N3 == 32) {
+        // both register halves lie in the same E row k1 (n3 and n3 + 16): one chain (twiddle16)
+        i32 k1 = sUl * GEO::SV + tau * GEO::G;
+        i32 n30 = hi * 4;
+        if constexpr (RP) {
+          i32 kk = k1 * ps.R + ps.k0;
+          twiddle16(re, im, B::mul24(mlane + n30, kk), kk, 1.0f, s_inv, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+        } else {
+          twiddle16(re, im, B::mul24(mlane + n30, k1), k1, 1.0f, s_inv);
         }
       } else
 #pragma unroll
@@ -1617,6 +1799,17 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
+    if constexpr (GEO::N3 == 32) {       // one chain for both register halves (twiddle16)
+      i32 k1 = sUl * GEO::SV + tau * GEO::G;
+      i32 n30 = hi * 4;
+      if constexpr (RP) {
+        i32 kk = k1 * ps.R + ps.k0;
+        twiddle16(re, im, B::mul24(mlane + n30, kk), kk, 1.0f, s_inv, GEO::N * ps.R - 1, 1.0f / (float)(GEO::N * ps.R));
+      } else {
+        twiddle16(re, im, B::mul24(mlane + n30, k1), k1, 1.0f, s_inv);
+      }
+      return;
+    }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       const int sV = (16 * half) / GEO::N3;
@@ -1747,6 +1940,19 @@ struct Body {
       const i32 lane = B::opaque(B::lane());
       const i32 c = lane & 31, hi = lane >> 5;
       const i32 sUl = c / GEO::N2, mlane = (c % GEO::N2) * GEO::N3;
+      if constexpr (GEO::N3 == 32 && FFC_CHAIN16 != 0) {      // fft 16384: the second half is the first one times w^16 (see twiddle16)
+        i32 k1 = sUl * GEO::SV + tau * GEO::G;
+        F2 tr[4], ti[4];
+        f32 c8, s8;
+        chain8p(B::mul24(mlane + hi * 4, k1), k1, 1.0f, a.s_inv, tr, ti, GEO::N - 1, 1.0f / (float)GEO::N, &c8, &s8);
+        apply8(reA, imA, 0, tr, ti);
+        apply8(reB, imB, 0, tr, ti);
+        const f32 c16 = c8 * c8 - s8 * s8, s16 = (c8 + c8) * s8;
+#pragma unroll
+        for (int i = 0; i < 4; i++) B::cmulp(tr[i], ti[i], c16, s16, tr[i], ti[i]);
+        apply8(reA, imA, 1, tr, ti);
+        apply8(reB, imB, 1, tr, ti);
+      } else
 #pragma unroll
       for (int half = 0; half < 2; half++) {
         const int sV = (16 * half) / GEO::N3;

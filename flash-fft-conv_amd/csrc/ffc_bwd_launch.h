@@ -44,14 +44,24 @@ __global__ __launch_bounds__(GEO::WGW * 64, 2) void bwd_kernel_small(DkfArgs d) 
     if (map_id(id, d.c.H, d.c.nchunk, &h, &chunk)) M::template bwd<false, false, false>(d, h, chunk, id);
   }
 }
-template <class GEO, int DT, bool HALF, int ZM>
+// FASTK: launched only when every tensor is 16-byte aligned and L % 8 == 0 (DkfArgs::c.fast): the row code exists once, as 16-byte
+// accesses (DevBOF); FASTK = false keeps the run-time switch for ragged / misaligned calls
+template <class GEO, int DT, bool HALF, int ZM, bool FASTK>
 __global__ __launch_bounds__(GEO::WGW * 64, 2) __attribute__((amdgpu_num_vgpr(128))) void bwd_rp_kernel(DkfArgs d) {
+  using BK = typename std::conditional<FASTK, DevBOF, DevBO>::type;
   int h, chunk;
   if (!map_block(d.c.H, d.c.nchunk, &h, &chunk)) return;
-  Modes<DevBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
+  Modes<BK, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
   const int wv = DevBO::wave(), wg = blockIdx.x;
 #pragma unroll 1
-  for (int k0 = 0; k0 < d.c.R; k0++) Modes<DevBO, GEO, DT>::template bwd<HALF, true, true, ZM>(d, h, chunk, wg, k0, wv);
+  for (int k0 = 0; k0 < d.c.R; k0++) Modes<BK, GEO, DT>::template bwd<HALF, true, true, ZM>(d, h, chunk, wg, k0, wv);
+}
+template <class K>
+static int ffc_bwd_rp_go(K kernel, int lds, dim3 grid, dim3 block, hipStream_t st, const DkfArgs& d) {
+  int rc = ffc_set_lds(kernel, lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, d);
+  return 0;
 }
 
 template <int ZM>
@@ -64,15 +74,13 @@ struct T {
     if (d.c.R > 1) {
       if constexpr (GEO::N == 32768) {
         const dim3 grid(ngrid), block(GEO::WGW * 64);
-        if (16 * GEO::Mi >= d.c.L) {
-          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, true, ZM>, GEO::LDS_BYTES);
-          if (rc) return rc;
-          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, true, ZM>), grid, block, GEO::LDS_BYTES, st, d);
-        } else {
-          int rc = ffc_set_lds(bwd_rp_kernel<GEO, DT, false, ZM>, GEO::LDS_BYTES);
-          if (rc) return rc;
-          hipLaunchKernelGGL((bwd_rp_kernel<GEO, DT, false, ZM>), grid, block, GEO::LDS_BYTES, st, d);
-        }
+        const bool half = 16 * GEO::Mi >= d.c.L;
+        int rc;
+        if (d.c.fast && (FFC_RP_FASTK != 0)) rc = half ? ffc_bwd_rp_go(bwd_rp_kernel<GEO, DT, true, ZM, true>, GEO::LDS_BYTES, grid, block, st, d)
+                                : ffc_bwd_rp_go(bwd_rp_kernel<GEO, DT, false, ZM, true>, GEO::LDS_BYTES, grid, block, st, d);
+        else rc = half ? ffc_bwd_rp_go(bwd_rp_kernel<GEO, DT, true, ZM, false>, GEO::LDS_BYTES, grid, block, st, d)
+                       : ffc_bwd_rp_go(bwd_rp_kernel<GEO, DT, false, ZM, false>, GEO::LDS_BYTES, grid, block, st, d);
+        if (rc) return rc;
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : ffc_fail(std::string("bwd_rp_kernel launch: ") + hipGetErrorString(e));
       } else if constexpr (GEO::OUTER) {

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 
 #define FFC_FN __device__ __forceinline__
 #include "../../include/flashfftconv_hip.h"
@@ -35,6 +36,7 @@ struct DevB {
   struct U2 { u32 x, y; };
   struct U4 { u32 x, y, z, w; };
   static constexpr bool LEAN_OUTER = false;
+  static constexpr bool FAST_ONLY = false;     // true: only the 16-byte arm of the row accesses is compiled (Body::gload8 / gstore8)
   using A16 = f32x16;   // 16 consecutive VGPRs/AGPRs: the MFMA accumulator tuple
   using W4 = u32x4v;    // 4 consecutive VGPRs: one MFMA A/B operand
   static constexpr bool HAS_TR = true;
@@ -331,6 +333,12 @@ struct DevBO : DevB {
     asm volatile("" : "+v"(x));
     return x;
   }
+};
+
+// DevBO for launches on 16-byte-aligned tensors with L % 8 == 0 only (the launcher checks: ConvArgs::fast): the multi-pass backward
+// kernels (fft 65536 / 131072) -- one copy of the row code per kernel, every row load of a batch in flight (round 5)
+struct DevBOF : DevBO {
+  static constexpr bool FAST_ONLY = true;
 };
 
 }  // namespace ffc

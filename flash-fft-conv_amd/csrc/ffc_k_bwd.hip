@@ -101,6 +101,14 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
     d.dk_fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
     *dk_done = true;
   }
+  // multi-pass sizes (fft 65536 / 131072, bf16 plans): every pass ends with its share of dk (Modes::dk_tail_rp); tuning flag 32 as above
+  if (dk && dk_done && !*dk_done && a.nchunk == 1 && p->hp.R > 1 && p->hp.N1 > 1 && p->hp.dtype == DT_BF16 && !(p->env_flags & 32) &&
+      Lk > 0 && Lk <= p->hp.N) {
+    d.dk_out = dk; d.Lk = (int)Lk; d.dk_scale = (float)(1.0 / p->hp.s_fwd);
+    d.tab_bf = p->d_blob_bf; d.t_bf = p->hp_bf.tabs;
+    d.dk_fast = (Lk % 4 == 0) && !((uintptr_t)dk & 15);
+    *dk_done = true;
+  }
   // ... as complex rows (ffc_conv_bwd_kx: first step of dk at the HBM-level sizes; always bf16, the caller's scale)
   if (dk_pair && dk_done && a.nchunk == 1 && p->hp.N >= ((p->env_flags & 128) ? 8192 : 16384) && p->hp.N <= 32768 && p->hp.R == 1 &&
       !(p->env_flags & 32) && !((uintptr_t)dk_pair & 15)) {

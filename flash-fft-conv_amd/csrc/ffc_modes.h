@@ -709,6 +709,32 @@ struct Modes : Body<B, GEO, DT> {
     B::lds_fence();
     dk_tail_rows(d, h, un);
   }
+  // Multi-pass sizes (round 5; fft 65536 / 131072, bf16 plans, one chunk per head): at the end of pass k0's pair loop the accumulation
+  // registers hold the WHOLE dk_f of the rows (head, k0), so the pass's share of dk -- what Modes::dkifft computes from the fp32 slab
+  // of that (head, pass) -- is inverted right here: tile_inv with the pass's twiddle phase, phase C with the pass's inverse outer-digit
+  // matrix, and dk_rows_out_rp adds it to the fp32 dk rows (the same wave wrote the earlier passes' sums: its own column slice).
+  // No slab (config L = 32K: 402 MB written and read back), no dk_f -> dk launch.
+  template <int T>
+  static FFC_FN void dk_tail_tile_rp(const DkfArgs& d, Unit un, const InnerRegs& R, Pass ps) {
+    A16 re, im;
+    w_acc_read<T, 0, 16>(d.dk_scale, re, im);
+    BD::template tile_inv<false, true>(d.c.s_inv, un.wq * GEO::TPW + T, R, un, re, im, 0, ps);
+  }
+  static FFC_FN void dk_tail_rp(const DkfArgs& d, int h, int wq, Pass ps) {
+    static_assert(GEO::UPW == 1 && WREG == GEO::TPW && GEO::TPW == 4 && DT == DT_BF16, "dk tail of a pass: one unit per workgroup, bf16 tables");
+    const Unit un = unit_of(0, wq);
+    B::barrier();              // the last pair's output rows have left the exchange buffer
+    InnerRegs R;
+    BD::template load_inner<false>(R, un);
+    dk_tail_tile_rp<0>(d, un, R, ps); dk_tail_tile_rp<1>(d, un, R, ps); dk_tail_tile_rp<2>(d, un, R, ps); dk_tail_tile_rp<3>(d, un, R, ps);
+    B::barrier();
+    BD::template outer_stage<false, false, true>(d.Lk, un, 1.0f, ps);
+    B::lds_fence();
+    DkArgs ka{};
+    ka.dk = d.dk_out; ka.H = d.c.H; ka.Lk = d.Lk; ka.fast = d.dk_fast; ka.R = d.c.R;
+    dk_rows_out_rp(ka, h, un, ps);
+    // (no barrier: the next pass starts with row loads and phase A inside the wave's own column slice, like the next pair of a pass)
+  }
   // Several units per workgroup (fft 4096 / 8192 / 16384: UPW pairs of the same head, each with its own sums): tile by tile every
   // wave parks its 32 accumulators in the upper half of the (idle) exchange buffers, unit 0's waves add the units up in a fixed
   // order -- straight into accumulator-shaped registers -- and invert the tile into unit 0's buffer, which lies in the lower half.
@@ -1214,6 +1240,9 @@ struct Modes : Body<B, GEO, DT> {
           else MB::dk_tail_multi(d, h, u, un.wq);
           return;
         }
+      }
+      if constexpr (RP && WREG == GEO::TPW && GEO::NW > 1 && GEO::UPW == 1 && DT == DT_BF16) {
+        if (d.dk_out) { dk_tail_rp(d, h, un.wq, ps); return; }      // this pass's share of dk from the accumulation registers (nchunk == 1)
       }
       w_acc_finish(slab, u, un, W);
     } else if (a.R > 1) {

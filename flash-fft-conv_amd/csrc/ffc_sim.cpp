@@ -62,6 +62,7 @@ static inline uint16_t f32_to_dt(int DT, float f) { return DT == DT_BF16 ? f32_t
 
 struct SimB {
   static constexpr bool LEAN_OUTER = false;
+  static constexpr bool FAST_ONLY = false;
   using f32 = Vec<float>;
   using i32 = Vec<int>;
   using u32 = Vec<uint32_t>;
@@ -302,6 +303,7 @@ struct SimB {
 bool SimB::HAS_TR = true;
 // mirrors DevBO: the backward kernels use the per-tile outer stages
 struct SimBO : SimB { static constexpr bool LEAN_OUTER = true; };
+struct SimBOF : SimBO { static constexpr bool FAST_ONLY = true; };      // the fast-only instantiation of the multi-pass backward (DevBOF)
 static bool g_force_slow = false;
 
 // Run `fn(wg_index)` for one workgroup of nwaves wavefronts with lds_bytes of LDS.
@@ -436,7 +438,10 @@ template <class GEO, int DT> struct BwdRun {
               Modes<SimBO, GEO, DT>::BD::setup_tables(d.c.tab, d.c.t);
               const bool half = 16 * GEO::Mi >= d.c.L;
               for (int k0 = 0; k0 < d.c.R; k0++) {
-                if (half) Modes<SimBO, GEO, DT>::template bwd<true, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+                if (d.c.fast && (FFC_RP_FASTK != 0)) {      // the launcher's fast-only kernel (bwd_rp_kernel<.., FASTK = true>)
+                  if (half) Modes<SimBOF, GEO, DT>::template bwd<true, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+                  else Modes<SimBOF, GEO, DT>::template bwd<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
+                } else if (half) Modes<SimBO, GEO, DT>::template bwd<true, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
                 else Modes<SimBO, GEO, DT>::template bwd<false, true>(d, h, c, h * d.c.nchunk + c, k0, SimBO::wave());
               }
               return;
@@ -691,7 +696,7 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
     d.dk_pair = g_dk_pair; d.Lk = N; d.dk_scale = g_dk_pair_scale; d.dk_fast = 1;
     if (!build_plan(N, DT_BF16, &pbf)) return -1;
     d.tab_bf = pbf.blob.data(); d.t_bf = pbf.tabs;
-  } else if (g_dk_out && a.nchunk == 1 && N >= 8192 && N <= 32768) {
+  } else if (g_dk_out && a.nchunk == 1 && ((N >= 8192 && N <= 32768) || (p.R > 1 && p.N1 > 1 && dtype == DT_BF16))) {
     d.dk_out = g_dk_out; d.Lk = g_dk_lk; d.dk_scale = (float)(1.0 / p.s_fwd); d.dk_fast = (g_dk_lk % 4 == 0) && !g_force_slow;
     if (!build_plan(N, DT_BF16, &pbf)) return -1;
     d.tab_bf = pbf.blob.data(); d.t_bf = pbf.tabs;

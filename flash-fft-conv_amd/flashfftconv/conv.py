@@ -187,9 +187,18 @@ def _free_bytes(device):
     return c
 
 
+def _capturing():
+    try:
+        return torch.cuda.is_current_stream_capturing()
+    except Exception:          # no device (host-logic tests)
+        return False
+
+
 def _spectrum_budget_ok(nbytes, device, mode=True):
     if mode == "always" or nbytes <= _SPEC_SMALL:
         return True
+    if _capturing():      # graph capture (flashfftconv/graphs.py): no hipMemGetInfo under capture; the graph's private pool decides,
+        return True       # and an OutOfMemoryError still falls back
     c = _free_bytes(device)
     if nbytes > _SPEC_FRACTION * c[0]:
         return False
@@ -438,7 +447,9 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
             y = ops.conv(dt, M, x, kf, False)
     out = torch.empty_like(u)
     _big.levels_inverse(ops, dt, N, y, out, B, H, L, postgate, None, fac)
-    return out, kf, ((x, z, y if pregate is not None else None) if keep else None)
+    # kept for the backward pass: the inner spectra z; the inner input rows x only when there are no spectra (the saved-spectra inner
+    # kernel never reads them: round 5, a third of the kept bytes less); gated: the inner output y
+    return out, kf, ((x if z is None else None, z, y if pregate is not None else None) if keep else None)
 
 
 def _big_dk_from_dkf(mod, dkf, k_len, fac=None):
@@ -460,6 +471,11 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
     M = (fac or _big.BIG_FACTORS[N])[1]
     xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate, fac)
     xu, z, yu = kept if kept is not None else (_big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac), None, None)
+    if xu is None:
+        if z is None or (pregate is not None and yu is None):      # (cannot happen with what _big_forward keeps)
+            xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
+        else:
+            xu = xd       # stand-in of the same shape: with the inner spectra the (ungated) inner kernel does not read its input rows
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
     if not want_dkf and mod._kf_keep is None and _BIG_ONE_CALL:
@@ -543,8 +559,8 @@ class _FlashFFTConvFn(torch.autograd.Function):
         kept = None
         if ctx.big:
             keep = mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
-            if keep:      # kept: inner-size rows x (4 B per point and pair), their spectra z (4 B), gated also the inner output y (4 B)
-                keep = _spectrum_budget_ok(((u.shape[0] + 1) // 2) * u.shape[1] * mod.seqlen * (12 if ctx.gated else 8), u.device, mod.save_spectrum)
+            if keep:      # kept: the inner spectra z (4 B per point and pair), gated also the inner output y (4 B)
+                keep = _spectrum_budget_ok(((u.shape[0] + 1) // 2) * u.shape[1] * mod.seqlen * (8 if ctx.gated else 4), u.device, mod.save_spectrum)
                 if not keep:
                     SPECTRUM_FALLBACKS["budget"] += 1
             # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
@@ -721,6 +737,13 @@ class FlashFFTConv(torch.nn.Module):
         # "always" (FFC_SAVE_SPECTRUM=always): whenever the allocation succeeds; False: never (the reference's footprint)
         _sv = _os.environ.get("FFC_SAVE_SPECTRUM", "1")
         self.save_spectrum = False if _sv == "0" else ("always" if _sv == "always" else True)
+
+    def graphed_step(self, u, k, dout, pregate=None, postgate=None, warmup=3):
+        """forward + backward of this module captured into ONE HIP graph on static copies of the given tensors
+        (flashfftconv/graphs.py GraphedStep): for the short sequences, where a step is bound by the host side of autograd and
+        of the launches, not by its 30 - 50 us of kernels.  step(u, k, dout) -> (y, du, dk[, dpregate, dpostgate])."""
+        from .graphs import GraphedStep
+        return GraphedStep(self, u, k, dout, pregate, postgate, warmup)
 
     def _route_big(self, Lmax):
         """Per-call routing of fft 131072 (round 4, profiles/r04_route.txt, B16 H768 / H384, fwd + bwd ms): 4 passes of the fused 32768

@@ -348,7 +348,7 @@ class _BigOps:
 
     def conv_keep(self, u, kf, pre, post):
         keep = bool(self.mod.save_spectrum) and self.C._spectrum_budget_ok(
-            ((u.shape[0] + 1) // 2) * u.shape[1] * self.mod.seqlen * (12 if pre is not None else 8), u.device, self.mod.save_spectrum)
+            ((u.shape[0] + 1) // 2) * u.shape[1] * self.mod.seqlen * (8 if pre is not None else 4), u.device, self.mod.save_spectrum)
         try:
             out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, keep, kf, self.fac)
         except torch.cuda.OutOfMemoryError:      # same retry as the single-rank module

@@ -8,7 +8,9 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(os.path.dirname(HERE), "flash-fft-conv_amd")
-ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1"]
+# round 5: FFC_OUTER_QUAD = 0 is the tile-pair form of phases A / C (4-byte LDS accesses), FFC_RP_FASTK = 0 the multi-pass backward with the
+# run-time access-width switch in every row access (the default launches a 16-byte-only instantiation on aligned tensors)
+ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0"]
 
 
 def _alt_sim():
@@ -25,7 +27,8 @@ def _alt_sim():
 
 
 CASES = [(256, 200, 5, 2, 1, True), (1024, 1024, 3, 2, 0, True), (2048, 1024, 4, 1, 0, True), (4096, 2048, 5, 1, 1, True),
-         (32768, 16384, 3, 1, 0, False), (32768, 9000, 2, 1, 0, True), (65536, 32768, 3, 1, 0, True), (65536, 40004, 1, 1, 1, False)]
+         (32768, 16384, 3, 1, 0, False), (32768, 9000, 2, 1, 0, True), (65536, 32768, 3, 1, 0, True), (65536, 40004, 1, 1, 1, False),
+         (65536, 65536, 2, 1, 0, True), (131072, 65536, 1, 1, 0, False), (8192, 4096, 3, 1, 1, True), (16384, 16384, 2, 1, 0, False)]
 _SCRIPT = r'''
 import sys, hashlib, numpy as np
 sys.path[:0] = [%r, %r, %r]

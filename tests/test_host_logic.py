@@ -77,3 +77,66 @@ def test_loads_in_flight_audit_of_the_build():
                     build.check_load_runs(f.name, rules)
         finally:
             os.unlink(f.name)
+
+
+# ---------------------------------------------------------------- round 5: ADVICE r04
+class _StubLib:
+    def __init__(self):
+        self.reloaded = []
+
+    def ffc_plan_reload_env(self, handle):
+        self.reloaded.append(handle)
+
+    def ffc_spectrum_bytes(self, handle, B, H):
+        return 64 << 20
+
+
+def test_reload_env_drops_the_cached_workspace_sizes(monkeypatch):
+    """the dk_f workspace size depends on FFC_WG_MULT (chunks per head): a stale cache after reload_env would hand the backward kernel
+    a workspace that is too small"""
+    from flashfftconv import conv as C, _lib
+    stub = _StubLib()
+    monkeypatch.setattr(_lib, "lib", lambda: stub)
+
+    class P:
+        handle = 7
+    p = P()
+    p._ws_cache = {(16, 768): 123}
+    monkeypatch.setitem(C._PLANS, ("test", 0, 0), p)
+    C.reload_env()
+    assert stub.reloaded == [7] and not hasattr(p, "_ws_cache")
+
+
+def test_spectrum_fallbacks_are_counted_and_the_budget_is_charged_once(monkeypatch):
+    """a refused spectrum buffer is counted (benchmarks can assert which backward ran); the inner buffers of the HBM-level path
+    pass mode "always" because the module-level test already charged them"""
+    from flashfftconv import conv as C, _lib
+    monkeypatch.setattr(_lib, "lib", lambda: _StubLib())
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda idx=None: (128 << 20, 288 << 30))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda idx=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda idx=None: 0)
+    C._free_cache.clear()
+
+    class Plan:
+        seqlen, handle = 32768, 1
+    before = dict(C.SPECTRUM_FALLBACKS)
+    dev = torch.device("cuda", 0)
+    assert C._spectrum_buffer(Plan(), 16, 768, dev, True, True) is None          # 64 MB of 128 MB free: over 1/8 -> refused, counted
+    assert C.SPECTRUM_FALLBACKS["budget"] == before["budget"] + 1
+    free_after = C._free_cache[0][0]
+    alloc = []
+    monkeypatch.setattr(torch, "empty", lambda n, **kw: alloc.append(n) or "buf")
+    assert C._spectrum_buffer(Plan(), 16, 768, dev, True, "always") == "buf" and alloc == [64 << 20]
+    assert C._free_cache[0][0] == free_after                                     # "always": nothing charged a second time
+
+
+def test_fft_131072_route_is_shared_by_the_wrappers():
+    """fft 131072 takes the HBM-level form for rows longer than N/2; the B-shard and the Hyena operator must pick their kernels by
+    the same rule as the single-rank module"""
+    from flashfftconv import FlashFFTConv
+    import inspect
+    from flashfftconv import sharding, hyena
+    m = FlashFFTConv(131072, dtype=torch.bfloat16)
+    assert not m._big and not m._route_big(65536) and m._route_big(65537)
+    assert "_route_big" in inspect.getsource(sharding.BatchShardedFFTConv.forward)
+    assert "_route_big" in inspect.getsource(hyena.gated_conv_from_slices)

@@ -447,6 +447,25 @@ def test_dk_from_the_backward_launch(N, L, B, H, gated, Lk, dt):
     assert rel(dk1, r[1][:, :Lk]) < 1.5 * TOL[0]
 
 
+# ... and at the multi-pass sizes (round 5, Modes::dk_tail_rp; bf16 plans): every pass of the backward kernel ends with its share of dk,
+# added to the fp32 dk rows by the wave that wrote the earlier passes' sums -- no slab per (head, pass), no dkifft launch
+@pytest.mark.parametrize("N,L,B,H,gated,Lk", [(65536, 32768, 3, 1, False, 32768), (65536, 65536, 2, 1, True, 65536), (65536, 20000, 2, 2, False, 333),
+                                              (131072, 65536, 1, 1, False, 65536)])
+def test_dk_from_the_multi_pass_backward_launch(N, L, B, H, gated, Lk):
+    dt = 0
+    rng = np.random.default_rng(L + B + Lk)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, Lk)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    du0, dpre0, dk0 = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, Lk, pre, post, 1)
+    du1, dpre1, dk1 = S.sim_bwd(N, dt, S.to_bits(d, dt), S.to_bits(u, dt), kf, Lk, pre, post, 1, fused_dk=True)
+    assert np.array_equal(du0, du1) and (not gated or np.array_equal(dpre0, dpre1))
+    # the same fp32 sums through the same inverse: the slab path rounds nothing in between, so the two agree to the last bit
+    assert not np.isnan(dk1).any() and np.array_equal(dk1, dk0)
+
+
 # ---------------------------------------------------------------- k -> k_f inside the forward launch (Modes::kfft_head, ConvArgs::kfuse_k)
 @pytest.mark.parametrize("N,L,B,H,gated,Lk", [(32768, 16384, 4, 2, False, 16384), (32768, 32768, 2, 1, True, 32768), (32768, 9000, 3, 2, False, 700),
                                               (32768, 16384, 2, 1, False, 16381),
