@@ -24,3 +24,6 @@ cd $R
 python benchmarks/hyena_dna_fwd.py --train tiny-16k small-32k hyena-pile-4k > $O/hyena_train.jsonl 2> $O/hyena_train.err
 python benchmarks/short_probe.py > $O/short_probe.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; find $O -name "*counter_collection.csv" | head -3
+# the full GPU suite on the same (final) code: the driver's round-end command
+cd $R
+( time python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.txt 2>&1; tail -4 $O/pytest_gpu.txt

@@ -72,3 +72,9 @@ pmc("c", "conv_kernel", "r05_pmc_conv_kernel.txt", "benchmarks/prof_step_kernels
     906 + 805 + 50, "u 403 + y 403 + k_f written and read 101 + k 50 + saved spectra 805")
 pmc("b", "bwd_kernel", "r05_pmc_bwd_kernel.txt", "benchmarks/prof_step_kernels.py bwd: bwd_kernel<Geo<32,32,32>,bf16,HALF,ZM=1> fused backward on saved spectra incl. the dk tail (dout rows by LDS-DMA)", 906 + 50 + 805,
     "dout 403 + du 403 + k_f 101 + dk 50 (fp32; the dk_f sums never leave the registers) + saved spectra 805")
+
+# the GPU suite on the measured code (the driver's round-end command)
+pg = f"{O}/pytest_gpu.txt"
+if os.path.exists(pg):
+    keep = [l for l in open(pg) if " passed" in l or " failed" in l or l.startswith("real")]
+    open(f"{P}/r05_pytest_gpu.txt", "w").write("# python -m pytest tests -m gpu -x -q on the final round-5 code (benchmarks/measure_r05.sh)\n" + "".join(keep))
