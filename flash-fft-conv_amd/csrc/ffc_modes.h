@@ -781,9 +781,20 @@ struct Modes : Body<B, GEO, DT> {
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
   // accumulator registers are addressed statically.
-  template <bool WITH_DX, bool RP = false>
+  // FFC_Z_PREFETCH (build switch, round-5 experiment): the spectrum tile of iteration tt + 1 is requested right behind the last use of
+  // tile tt's (the accumulation), so that it is in flight under this tile's inverse half and the next tile's forward half; k_f behind the
+  // transform (the FFC_KF_LATE placement): 16 loop-carried registers instead of the 32 that failed the accumulation-register audit in round 4
+#ifndef FFC_Z_PREFETCH
+#define FFC_Z_PREFETCH 0
+#endif
+  template <bool WITH_DX, bool RP = false, bool ZSAVED = false>
   static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W,
                                Pass ps = Pass(), bool z_stream = false, bool second = false) {
+    // (fft 32768 geometry only: with it the one-wave-per-unit kernel of fft 4096 parks values in a0..a5, build.py check_agpr)
+    // (... and not the multi-pass or the recomputing kernels: their allocation reaches into a0..a11 with it)
+    constexpr bool PF = FFC_Z_PREFETCH != 0 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW) && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
+    typename BD::KfRegs zv;
+    if constexpr (PF) z_load(zs, un.wq * GEO::TPW, zv, z_stream || (a.flags & 4) != 0);
 #pragma unroll 1
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
@@ -792,28 +803,31 @@ struct Modes : Body<B, GEO, DT> {
         if (tt == GEO::TPW / 2) { if (second) B::template setprio<2>(); else B::template setprio<1>(); }
       }
 #endif
-      typename BD::KfRegs zv;
-      z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
+      if constexpr (!PF) z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
       typename BD::KfRegs kf;
-      // FFC_KF_LATE=1 (build switch, OFF; prepared for round 5, not measured): the k_f tile requested BEHIND the transform instead of next
-      // to the spectrum tile -- four load tuples instead of eight live across tile_fwd, where the allocator copies them out of the way of
-      // the MFMA operands and waits for them.
-      if constexpr (WITH_DX && FFC_KF_LATE == 0) BD::load_kf(a, h, tau, kf);
+      // FFC_KF_LATE=1 (build switch, OFF; measured in round 5: no effect, profiles/r05_ab_kf_late.txt): the k_f tile requested BEHIND the
+      // transform instead of next to the spectrum tile -- four load tuples instead of eight live across tile_fwd
+      constexpr bool KFL = FFC_KF_LATE != 0 || PF;
+      if constexpr (WITH_DX && !KFL) BD::load_kf(a, h, tau, kf);
       A16 re, im;
       if (WREG >= GEO::TPW || tt < WREG) {
         BD::template tile_fwd<false>(tau, R, un, re, im);
-        if constexpr (WITH_DX && FFC_KF_LATE != 0) BD::load_kf(a, h, tau, kf);
+        if constexpr (WITH_DX && KFL) BD::load_kf(a, h, tau, kf);
         switch (tt) {
           case 0: if constexpr (WREG > 0) w_acc_tile<0>(zv, re, im); break;
           case 1: if constexpr (WREG > 1) w_acc_tile<1>(zv, re, im); break;
           case 2: if constexpr (WREG > 2) w_acc_tile<2>(zv, re, im); break;
           default: if constexpr (WREG > 3) w_acc_tile<3>(zv, re, im); break;
         }
+        if constexpr (PF) {      // next tile's spectrum (clamped on the last iteration: a harmless re-read of this tile)
+          const int tn = tt + 1 < GEO::TPW ? tau + 1 : tau;
+          z_load(zs, tn, zv, z_stream || (a.flags & 4) != 0);
+        }
       } else {
         WOld wold;
         w_load_old(slab, tau, first, wold);
         BD::template tile_fwd<false>(tau, R, un, re, im);
-        if constexpr (WITH_DX && FFC_KF_LATE != 0) BD::load_kf(a, h, tau, kf);
+        if constexpr (WITH_DX && KFL) BD::load_kf(a, h, tau, kf);
         w_update(slab, tau, wold, zv, re, im);
       }
       if constexpr (WITH_DX) {
@@ -1191,7 +1205,7 @@ struct Modes : Body<B, GEO, DT> {
         FFC_BPRIO(3)
         if (act) {
           BD::template load_inner<false>(R, un);
-          bwd_tiles<true, RP>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z && FFC_Z_STREAM, second);
+          bwd_tiles<true, RP, ZM == 1>(a, hk, un, R, zp, slab, it == 0, W, ps, have_z && FFC_Z_STREAM, second);
         } else if (it == 0) {
 #pragma unroll 1
           for (int tt = WREG; tt < GEO::TPW; tt++) w_zero(slab, un.wq * GEO::TPW + tt);
