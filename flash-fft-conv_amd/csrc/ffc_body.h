@@ -171,6 +171,40 @@ struct Body {
         o.i[ms][d] = B::template pack<DT>(im[8 * ms + 2 * d], im[8 * ms + 2 * d + 1]);
       }
   }
+  // Folded-twiddle matrices (FFC_FOLD_TW): only the (Fr, Fi) forms are loaded (16 registers, 4 KB of L2 traffic instead of 24 / 6 KB);
+  // the -Fi product is Fi times the negated imaginary operand (sign bits flipped: 4 v_xor per K-step)
+  struct Mat2 { W4 w[2][2]; };
+  static FFC_FN void load_mat2_issue(Mat2& m, const uint8_t* p, i32 lane) {
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++)
+#pragma unroll
+      for (int f = 0; f < 2; f++) {
+        U4 v = B::g_r128(p, lane + (ms * 3 + f) * 64);
+        m.w[ms][f] = B::w4(v.x, v.y, v.z, v.w);
+      }
+  }
+  static FFC_FN W4 neg4(const W4& x) {
+    return B::w4(x[0] ^ B::uconst(0x80008000u), x[1] ^ B::uconst(0x80008000u), x[2] ^ B::uconst(0x80008000u), x[3] ^ B::uconst(0x80008000u));
+  }
+  // acc += F (x) data for a full complex matrix F = Fr + i Fi (conjugation, if any, is in the table)
+  template <bool AFORM>
+  static FFC_FN void cmm2(A16& ore, A16& oim, const Op& d, const Mat2& F) {
+#pragma unroll
+    for (int ms = 0; ms < 2; ms++) {
+      const W4 ni = neg4(d.i[ms]);
+      if (AFORM) {
+        B::template mfma<DT>(ore, d.r[ms], F.w[ms][0]);
+        B::template mfma<DT>(oim, d.r[ms], F.w[ms][1]);
+        B::template mfma<DT>(ore, ni, F.w[ms][1]);
+        B::template mfma<DT>(oim, d.i[ms], F.w[ms][0]);
+      } else {
+        B::template mfma<DT>(ore, F.w[ms][0], d.r[ms]);
+        B::template mfma<DT>(oim, F.w[ms][1], d.r[ms]);
+        B::template mfma<DT>(ore, F.w[ms][1], ni);
+        B::template mfma<DT>(oim, F.w[ms][0], d.i[ms]);
+      }
+    }
+  }
   // element-wise complex multiplies on whole accumulator tuples: the device backend issues them as packed
   // fp32 math (v_pk_mul_f32 / v_pk_fma_f32 on register pairs = half the VALU issue slots).
   static FFC_FN void cmul(A16& re, A16& im, const CT16& t) { B::template cmul16<false>(re, im, t.re, t.im); }
@@ -1073,7 +1107,7 @@ struct Body {
   // s1*128 + 4j + t.  FWD: rows are n1 (real pair x), result rows k1 with the W_N^{m k1} twiddle.
   // !FWD: rows are k1, result rows n1 (re -> batch row 2p, im -> row 2p+1).
   // HALF: input rows n1 >= 16 are all zero (L <= 16*Mi, 32-point outer digit) -> one K-step.
-  template <bool FWD, bool HALF, bool RP = false>
+  template <bool FWD, bool HALF, bool RP = false, bool NOTW = false>
   static FFC_FN void outer_stage_tile(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
@@ -1120,7 +1154,7 @@ struct Body {
       A16 re, im;
       re = B::a16_zero(); im = B::a16_zero();
       cmm<!FWD, false>(re, im, op, F1, ms_lim);
-      if (FWD) {
+      if (FWD && !NOTW) {
         // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
         if constexpr (CHAIN16_A && FFC_CHAIN16_TILE) {              // both halves share the column m: one chain (twiddle16)
           i32 m = j * 4 + (w * 128 * GEO::S1 + t);
@@ -1162,7 +1196,7 @@ struct Body {
   // (the first tile's fp32 accumulators wait for the second tile's instead of a stash of packed halves).
   // No length masks: every E row this stage reads was written by rows_store, zero beyond L (HALF never reads rows >= 16).
   // DIN: the input rows were copied by LDS-DMA into E rows 16.. in natural layout (rows_dma)
-  template <bool FWD, bool HALF, bool RP = false, bool DIN = false>
+  template <bool FWD, bool HALF, bool RP = false, bool DIN = false, bool NOTW = false>
   static FFC_FN void outer_stage_pair(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
     static_assert(!DIN || (FWD && HALF && HAS_DMA && !RP), "DMA input rows: forward stage of the half-empty 32-point digit");
     const i32 lane = B::opaque(B::lane());
@@ -1212,7 +1246,7 @@ struct Body {
         A16 re, im;
         re = B::a16_zero(); im = B::a16_zero();
         cmm<!FWD, false>(re, im, op, F1, ms_lim);
-        if (FWD) {
+        if (FWD && !NOTW) {
           // s_fwd * W_N^{m*k1}: registers <-> rows k1 = 4*hi + {0..3} + 8*{0..3} (mod N1), lane/tile <-> column m
           if constexpr (CHAIN16_A) {              // both halves share the column m: one chain (twiddle16)
             i32 m = j * 4 + (w * 128 * GEO::S1 + 2 * tp + th);
@@ -1287,7 +1321,7 @@ struct Body {
 #ifndef FFC_OUTER_QUAD
 #define FFC_OUTER_QUAD 1
 #endif
-  template <bool FWD, bool HALF, bool RP = false>
+  template <bool FWD, bool HALF, bool RP = false, bool NOTW = false>
   static FFC_FN void outer_stage_quad(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
     const i32 lane = B::opaque(B::lane());
     const int w = un.wq;
@@ -1334,7 +1368,7 @@ struct Body {
         A16 re, im;
         re = B::a16_zero(); im = B::a16_zero();
         cmm<!FWD, false>(re, im, op, F1, ms_lim);
-        if (FWD) {
+        if (FWD && !NOTW) {
           if constexpr (CHAIN16_A) {
             i32 m = j * 4 + (w * 128 * GEO::S1 + 2 * tp + th);
             i32 k0 = hi * 4;
@@ -1378,9 +1412,10 @@ struct Body {
 
   // The forward/dx kernels take the tile-pair variant (fastest); the backward kernels, which run on the
   // architectural half of the register file, take the per-tile one (B::LEAN_OUTER).
-  template <bool FWD, bool HALF, bool RP = false, bool DIN = false>
+  // NOTW: no outer twiddle behind the forward DFT (FFC_FOLD_TW: it is folded into the inner stages' per-tile matrices, tile_fwd<.., FOLD>)
+  template <bool FWD, bool HALF, bool RP = false, bool DIN = false, bool NOTW = false>
   static FFC_FN void outer_stage(int L, Unit un, float s_fwd = 1.0f, Pass ps = Pass()) {
-    if constexpr (DIN) { outer_stage_pair<FWD, HALF, RP, true>(L, un, s_fwd, ps); return; }
+    if constexpr (DIN) { outer_stage_pair<FWD, HALF, RP, true, NOTW>(L, un, s_fwd, ps); return; }
 #if defined(FFC_KO) && (FFC_KO & 8)
     return;
 #endif
@@ -1388,12 +1423,12 @@ struct Body {
 #define FFC_LEAN_TILE 0
 #endif
     // backward kernels (128-VGPR budget): the tile-pair form only fits with one K-step of raw rows (half-empty outer digit)
-    if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF && GEO::N1 == 32))) outer_stage_tile<FWD, HALF, RP>(L, un, s_fwd, ps);
+    if constexpr (B::LEAN_OUTER && (FFC_LEAN_TILE || !(FWD && HALF && GEO::N1 == 32))) outer_stage_tile<FWD, HALF, RP, NOTW>(L, un, s_fwd, ps);
     // (HALF kernels only: same box, round 5 -- forward -1 ... -3 % at L <= N/2 (config 2 0.4474 -> 0.4334 ms with the chain change, gated
     // fft 16384 -2.8 %), but the full-length spectrum-saving forward came out 5 % SLOWER with it (0.695 -> 0.730 ms, no spills: 28 more
     // live registers through phase C), the full-length plain forward 1.5 % faster: profiles/r05_ab_kernels.txt)
-    else if constexpr (!B::LEAN_OUTER && FFC_OUTER_QUAD != 0 && HALF) outer_stage_quad<FWD, HALF, RP>(L, un, s_fwd, ps);
-    else outer_stage_pair<FWD, HALF, RP>(L, un, s_fwd, ps);
+    else if constexpr (!B::LEAN_OUTER && FFC_OUTER_QUAD != 0 && HALF) outer_stage_quad<FWD, HALF, RP, NOTW>(L, un, s_fwd, ps);
+    else outer_stage_pair<FWD, HALF, RP, false, NOTW>(L, un, s_fwd, ps);
   }
 
   // ------------------------------------------------------------------ phase B (inner tile)
@@ -1485,8 +1520,35 @@ struct Body {
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
   // TWR: inner twiddle table resident in registers (R.tw); false -> re-read from LDS at each use (saves 32
   // VGPRs in the register-heavy backward kernels)
-  template <bool TWR = true, bool IP = false>
-  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im, const InnerPass* ip = nullptr) {
+  // FFC_FOLD_TW (round 5, build switch): the outer twiddle W_N^{m k1}, m = 32 n2 + n3, is the product of a factor on n2 and one on n3,
+  // and each inner stage contracts (forward) resp. produces (inverse) exactly one of the two indices -- so both factors fold into
+  // the stages' DFT matrices, one 6 KB operand table per (stage, tile k1) from L2 (PlanTabs::fold, 768 KB per plan), and NO elementwise
+  // outer twiddle is left: no chain (v_sin / v_cos), no 16 complex multiplies per tile and direction.  s_fwd / s_inv ride in the
+  // stage-a matrices.  Geo<32,32,32>, single pass.  `fold` = plan blob + PlanTabs::fold.
+#ifndef FFC_FOLD_TW
+#define FFC_FOLD_TW 0
+#endif
+  static constexpr bool CAN_FOLD = FFC_FOLD_TW != 0 && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
+  template <bool TWR = true, bool IP = false, bool FOLD = false>
+  static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im, const InnerPass* ip = nullptr, const uint8_t* fold = nullptr,
+                              const Mat2* fa_pre = nullptr) {
+    if constexpr (FOLD) {
+      const i32 lane = B::opaque(B::lane());
+      Mat2 FA, FB;
+      if (fa_pre) FA = *fa_pre;                 // requested by the caller during the previous tile (one stage of lookahead)
+      else load_mat2_issue(FA, fold + (0 * 32 + tau) * 6144, lane);
+      load_mat2_issue(FB, fold + (1 * 32 + tau) * 6144, lane);
+      Op op;
+      load_tile_op(tau, op, un, R);
+      re = B::a16_zero(); im = B::a16_zero();
+      cmm2<true>(re, im, op, FA);
+      if constexpr (TWR) cmul(re, im, R.tw);
+      else cmul_lds<false>(re, im, GEO::L_TW);
+      to_op(re, im, op);
+      re = B::a16_zero(); im = B::a16_zero();
+      cmm2<false>(re, im, op, FB);
+      return;
+    }
     Op op;
     load_tile_op(tau, op, un, R);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
@@ -1514,11 +1576,41 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  template <bool TWR = true, bool RP = false, bool IP = false>
+  template <bool TWR = true, bool RP = false, bool IP = false, bool FOLD = false>
   static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0, Pass ps = Pass(),
-                              const InnerPass* ip = nullptr) {
+                              const InnerPass* ip = nullptr, const uint8_t* fold = nullptr, const Mat2* g_pre = nullptr) {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
+    if constexpr (FOLD) {
+      static_assert(!RP && !IP && CAN_FOLD, "folded outer twiddle: single-pass fft 32768");
+      Mat2 GB, GA;                  // conjugation and the outer inverse factors (+ s_inv) are in the tables: plain products
+      if (g_pre) { GB = g_pre[0]; GA = g_pre[1]; }      // requested by the caller behind the forward half
+      else {
+        load_mat2_issue(GB, fold + (2 * 32 + tau) * 6144, lane);
+        load_mat2_issue(GA, fold + (3 * 32 + tau) * 6144, lane);
+      }
+      Op op;
+      to_op(re, im, op);
+      re = B::a16_zero(); im = B::a16_zero();
+      cmm2<true>(re, im, op, GB);
+      if constexpr (TWR) cmul_conj(re, im, R.tw);
+      else cmul_lds<true>(re, im, GEO::L_TW);
+      to_op(re, im, op);
+      re = B::a16_zero(); im = B::a16_zero();
+      cmm2<true>(re, im, op, GA);
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        i32 off = R.woff[rq] + tau * (GEO::G * GEO::Mi * 2);
+        U2 vr, vi;
+        vr.x = B::template pack<DT>(re[4 * rq], re[4 * rq + 1]);
+        vr.y = B::template pack<DT>(re[4 * rq + 2], re[4 * rq + 3]);
+        vi.x = B::template pack<DT>(im[4 * rq], im[4 * rq + 1]);
+        vi.y = B::template pack<DT>(im[4 * rq + 2], im[4 * rq + 3]);
+        B::lds_w64(off, vr);
+        B::lds_w64(off + GEO::PLANE, vi);
+      }
+      return;
+    }
     Op op;
     to_op(re, im, op);
     // inverse stage b: contract k3 (A-form, conj) -> [U' regs][V''=(sV,n3) lanes]
@@ -1839,9 +1931,115 @@ struct Body {
     }
   }
   // SZ (compile time: phase B must stay one basic block): store both tiles' spectra at zs (ConvArgs::zsave)
-  template <bool RP = false, bool SZ = false>
+  // FFC_FOLD_TW form of inner_tile2 (see tile_fwd): every stage of either tile multiplies by its own per-(stage, tile) matrix from L2 with the
+  // outer twiddle folded in; the loads of a stage's two matrices are requested one stage ahead.  No oi_twiddle, and phase A ran without
+  // its twiddle (outer_stage<.., NOTW>).  LDSTW: inner twiddle streamed from LDS instead of the 32 resident registers.
+#ifndef FFC_FOLD_LDSTW
+#define FFC_FOLD_LDSTW 0
+#endif
+#ifndef FFC_FOLD_FWD
+#define FFC_FOLD_FWD 1      // (with FFC_FOLD_TW) 0: only the saved-spectra backward folds, the forward kernels keep the chains
+#endif
+  template <bool SZ>
+  static FFC_FN void inner_tile2_fold(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un, uint8_t* zs) {
+    static_assert(CAN_FOLD, "folded outer twiddle: fft 32768 geometry");
+    const int tauB = tauA + 1;
+    const i32 lane = B::opaque(B::lane());
+    const uint8_t* fold = a.tab + a.t.fold;
+    Mat2 FAa, FAb, FBa, FBb;
+    load_mat2_issue(FAa, fold + (0 * 32 + tauA) * 6144, lane);
+    load_mat2_issue(FAb, fold + (0 * 32 + tauB) * 6144, lane);
+    KfRegs kfA, kfB;
+    load_kf(a, h, tauA, kfA);
+    load_kf(a, h, tauB, kfB);
+    Op opA, opB;
+    load_tile_op(tauA, opA, un, R);
+    load_tile_op(tauB, opB, un, R);
+    load_mat2_issue(FBa, fold + (1 * 32 + tauA) * 6144, lane);
+    load_mat2_issue(FBb, fold + (1 * 32 + tauB) * 6144, lane);
+    A16 reA, imA, reB, imB;
+    auto tw_fwd = [&](A16& re, A16& im) { if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<false>(re, im, GEO::L_TW); else cmul(re, im, R.tw); };
+    auto tw_inv = [&](A16& re, A16& im) { if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<true>(re, im, GEO::L_TW); else cmul_conj(re, im, R.tw); };
+    // stage a
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<true>(reA, imA, opA, FAa);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<true>(reB, imB, opB, FAb);
+    tw_fwd(reA, imA); to_op(reA, imA, opA);
+    Mat2 GBa, GBb;
+    load_mat2_issue(GBa, fold + (2 * 32 + tauA) * 6144, lane);
+    load_mat2_issue(GBb, fold + (2 * 32 + tauB) * 6144, lane);
+    // stage b
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<false>(reA, imA, opA, FBa);
+    tw_fwd(reB, imB); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<false>(reB, imB, opB, FBb);
+    if constexpr (SZ) { z_store(zs, tauA, reA, imA, FFC_Z_STREAM); z_store(zs, tauB, reB, imB, FFC_Z_STREAM); }
+    // (x) k_f, inverse stage b
+    kf_mul<SZ>(a, kfA, reA, imA); to_op(reA, imA, opA);
+    Mat2 GAa, GAb;
+    load_mat2_issue(GAa, fold + (3 * 32 + tauA) * 6144, lane);
+    load_mat2_issue(GAb, fold + (3 * 32 + tauB) * 6144, lane);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<true>(reA, imA, opA, GBa);
+    kf_mul<SZ>(a, kfB, reB, imB); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<true>(reB, imB, opB, GBb);
+    // inverse inner twiddle, inverse stage a (outer inverse twiddle and s_inv are in GA)
+    tw_inv(reA, imA); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<true>(reA, imA, opA, GAa);
+    tw_inv(reB, imB); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<true>(reB, imB, opB, GAb);
+    tile_store(tauA, R, reA, imA);
+    tile_store(tauB, R, reB, imB);
+  }
+  // one tile at a time (FFC_FOLD_ONE: the L <= N/2 forward kernels, whose next pair's rows wait in 32 registers across phase B -- with two
+  // tiles' matrices in flight they spilled 60 .. 170 registers)
+#ifndef FFC_FOLD_ONE
+#define FFC_FOLD_ONE 2      // 0: two tiles in lock-step everywhere, 1: one tile at a time everywhere, 2: one at a time in the L <= N/2 kernels only
+#endif
+  template <bool SZ>
+  static FFC_FN void inner_tile1_fold(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un, uint8_t* zs) {
+    static_assert(CAN_FOLD, "folded outer twiddle: fft 32768 geometry");
+    const i32 lane = B::opaque(B::lane());
+    const uint8_t* fold = a.tab + a.t.fold;
+    Mat2 FA, FB, GB, GA;
+    load_mat2_issue(FA, fold + (0 * 32 + tau) * 6144, lane);
+    KfRegs kf;
+    load_kf(a, h, tau, kf);
+    Op op;
+    load_tile_op(tau, op, un, R);
+    load_mat2_issue(FB, fold + (1 * 32 + tau) * 6144, lane);
+    A16 re, im;
+    re = B::a16_zero(); im = B::a16_zero();
+    cmm2<true>(re, im, op, FA);
+    load_mat2_issue(GB, fold + (2 * 32 + tau) * 6144, lane);
+    if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<false>(re, im, GEO::L_TW); else cmul(re, im, R.tw);
+    to_op(re, im, op);
+    re = B::a16_zero(); im = B::a16_zero();
+    cmm2<false>(re, im, op, FB);
+    load_mat2_issue(GA, fold + (3 * 32 + tau) * 6144, lane);
+    if constexpr (SZ) z_store(zs, tau, re, im, FFC_Z_STREAM);
+    kf_mul<SZ>(a, kf, re, im); to_op(re, im, op);
+    re = B::a16_zero(); im = B::a16_zero();
+    cmm2<true>(re, im, op, GB);
+    if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<true>(re, im, GEO::L_TW); else cmul_conj(re, im, R.tw);
+    to_op(re, im, op);
+    re = B::a16_zero(); im = B::a16_zero();
+    cmm2<true>(re, im, op, GA);
+    tile_store(tau, R, re, im);
+  }
+  template <bool RP = false, bool SZ = false, bool FOLD = false, bool HALFK = false>
   static FFC_FN void inner_tile2(const ConvArgs& a, int h, int tauA, const InnerRegs& R, Unit un, Pass ps = Pass(), uint8_t* zs = nullptr) {
     static_assert(GEO::N3 == GEO::N2 && GEO::OUTER, "inner_tile2: fused sizes with one inner matrix");
+    if constexpr (FOLD) {
+      if constexpr (FFC_FOLD_ONE == 1 || (FFC_FOLD_ONE == 2 && HALFK)) { inner_tile1_fold<SZ>(a, h, tauA, R, un, zs); inner_tile1_fold<SZ>(a, h, tauA + 1, R, un, zs); }
+      else inner_tile2_fold<SZ>(a, h, tauA, R, un, zs);
+      return;
+    }
     const int tauB = tauA + 1;
     KfRegs kfA, kfB;
     load_kf(a, h, tauA, kfA);
@@ -1993,6 +2191,8 @@ struct Body {
     // phase B retire in order behind them and the tile loop has no registers to spare
     // (profiles/r01_phase_cycles.txt).
     constexpr bool PREFETCH = HALF && !RP;    // full-length rows: 64 row registers on top of phase C would spill
+    // FFC_FOLD_TW: forward / dx kernels of single-pass fft 32768 (not the frequency-sparse, profiling or dynamically scheduled variants)
+    constexpr bool FOLDF = CAN_FOLD && !RP && !SP && !PROF && !B::LEAN_OUTER && FFC_FOLD_FWD != 0;
 #if defined(FFC_NO_CROSS)
     constexpr bool CROSS = false;
 #else
@@ -2043,7 +2243,7 @@ struct Body {
         B::lds_fence();
         FFC_TICK(0)
         FFC_PRIO(0)
-        outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+        outer_stage<true, HALF, RP, false, FOLDF>(a.L, un, a.s_fwd, ps);
         FFC_TICK(1)
       }
       unit_barrier();
@@ -2115,7 +2315,7 @@ struct Body {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) {
             if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
-            inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
+            inner_tile2<RP, SZ, FOLDF, HALF>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
                                 SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr);
           }
 #endif

@@ -793,8 +793,15 @@ struct Modes : Body<B, GEO, DT> {
     // (fft 32768 geometry only: with it the one-wave-per-unit kernel of fft 4096 parks values in a0..a5, build.py check_agpr)
     // (... and not the multi-pass or the recomputing kernels: their allocation reaches into a0..a11 with it)
     constexpr bool PF = FFC_Z_PREFETCH != 0 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW) && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
+    // folded outer twiddle (Body::tile_fwd / tile_inv <.., FOLD>): the saved-spectra backward of single-pass fft 32768, whose phase A ran
+    // without the twiddle (Modes::bwd)
+    constexpr bool FOLD = BD::CAN_FOLD && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW);
+    const uint8_t* fold = FOLD ? a.tab + a.t.fold : nullptr;
     typename BD::KfRegs zv;
     if constexpr (PF) z_load(zs, un.wq * GEO::TPW, zv, z_stream || (a.flags & 4) != 0);
+    // FOLD: every matrix is requested one stage ahead of its use; the next tile's first matrix behind this tile's last stage (16 loop-carried registers)
+    typename BD::Mat2 fa;
+    if constexpr (FOLD) BD::load_mat2_issue(fa, fold + (un.wq * GEO::TPW) * 6144, B::opaque(B::lane()));
 #pragma unroll 1
     for (int tt = 0; tt < GEO::TPW; tt++) {
       const int tau = un.wq * GEO::TPW + tt;
@@ -807,11 +814,11 @@ struct Modes : Body<B, GEO, DT> {
       typename BD::KfRegs kf;
       // FFC_KF_LATE=1 (build switch, OFF; measured in round 5: no effect, profiles/r05_ab_kf_late.txt): the k_f tile requested BEHIND the
       // transform instead of next to the spectrum tile -- four load tuples instead of eight live across tile_fwd
-      constexpr bool KFL = FFC_KF_LATE != 0 || PF;
+      constexpr bool KFL = FFC_KF_LATE != 0 || PF || FOLD;
       if constexpr (WITH_DX && !KFL) BD::load_kf(a, h, tau, kf);
       A16 re, im;
       if (WREG >= GEO::TPW || tt < WREG) {
-        BD::template tile_fwd<false>(tau, R, un, re, im);
+        BD::template tile_fwd<false, false, FOLD>(tau, R, un, re, im, nullptr, fold, FOLD ? &fa : nullptr);
         if constexpr (WITH_DX && KFL) BD::load_kf(a, h, tau, kf);
         switch (tt) {
           case 0: if constexpr (WREG > 0) w_acc_tile<0>(zv, re, im); break;
@@ -831,8 +838,18 @@ struct Modes : Body<B, GEO, DT> {
         w_update(slab, tau, wold, zv, re, im);
       }
       if constexpr (WITH_DX) {
+        typename BD::Mat2 g[2];
+        if constexpr (FOLD) {        // the inverse half's matrices, in flight under the accumulation and the k_f product
+          const i32 lane = B::opaque(B::lane());
+          BD::load_mat2_issue(g[0], fold + (2 * 32 + tau) * 6144, lane);
+          BD::load_mat2_issue(g[1], fold + (3 * 32 + tau) * 6144, lane);
+        }
         kf_conj_mul(kf, re, im);
-        BD::template tile_inv<false, RP>(a.s_inv, tau, R, un, re, im, 0, ps);
+        if constexpr (FOLD) {        // next tile's first matrix (clamped on the last iteration)
+          const int tn = tt + 1 < GEO::TPW ? tau + 1 : tau;
+          BD::load_mat2_issue(fa, fold + tn * 6144, B::opaque(B::lane()));
+        }
+        BD::template tile_inv<false, RP, false, FOLD>(a.s_inv, tau, R, un, re, im, 0, ps, nullptr, fold, FOLD ? g : nullptr);
       }
     }
   }
@@ -1071,6 +1088,8 @@ struct Modes : Body<B, GEO, DT> {
       // space, parks them in the accumulation registers; warm-up loads into 4 registers did not shorten the wait either:
       // DESIGN.md section 7)
       const bool have_z = ZM < 0 ? d.zin != nullptr : ZM == 1;
+      // FFC_FOLD_TW: the saved-spectra kernel of single-pass fft 32768 runs phase A of dout without the outer twiddle (bwd_tiles folds it)
+      constexpr bool FOLDZ = BD::CAN_FOLD && ZM == 1 && !RP && (WREG >= GEO::TPW);
       // input rows of dout by LDS-DMA into the dead half of the exchange buffer (Body::rows_dma): saved-spectra form of the
       // HALF kernels with a 32-point outer digit, plain rows (no gate multiply / side product on the way in), 16-byte-aligned
       // tensors; tuning flag 8 (FFC_FLAGS) keeps the register path for A/B runs
@@ -1131,7 +1150,7 @@ struct Modes : Body<B, GEO, DT> {
                 BD::rows_dma_finish(ad, p, un);
                 FFC_BTICK(6)
                 FFC_BPRIO(0)
-                BD::template outer_stage<true, HALF, RP, true>(a.L, un, a.s_fwd, ps);
+                BD::template outer_stage<true, HALF, RP, true, FOLDZ>(a.L, un, a.s_fwd, ps);
                 done = true;
               }
             }
@@ -1141,7 +1160,7 @@ struct Modes : Body<B, GEO, DT> {
               B::lds_fence();
               FFC_BTICK(6)
               FFC_BPRIO(0)
-              BD::template outer_stage<true, HALF, RP>(a.L, un, a.s_fwd, ps);
+              BD::template outer_stage<true, HALF, RP, false, FOLDZ>(a.L, un, a.s_fwd, ps);
             }
             FFC_BTICK(7)
           }

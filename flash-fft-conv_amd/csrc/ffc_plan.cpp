@@ -185,6 +185,32 @@ void fill_mat_pass(uint8_t* dst, int Nd, int dtype, int k0, int R, bool inverse)
         }
 }
 
+// Per-tile inner matrices with the outer twiddle folded in (PlanTabs::fold; Geo<32,32,32>, tile = k1).  out = lane's (non-contracted)
+// index, con = contraction index; the extra factor exp(-+ 2 pi i x k1 mult / N) sits on x = con (forward stages: input index) or
+// x = out (inverse stages: output index); mult = 32 for the n2 stages (m = 32 n2 + n3), 1 for the n3 stages.
+void fill_mat_fold(uint8_t* dst, int dtype, int which4, int k1, int N, double scale) {
+  uint32_t* w = (uint32_t*)dst;
+  const bool inverse = which4 >= 2;
+  const int mult = (which4 == 0 || which4 == 3) ? 32 : 1;
+  for (int ms = 0; ms < 2; ms++)
+    for (int which = 0; which < 3; which++)
+      for (int lane = 0; lane < 64; lane++)
+        for (int d = 0; d < 4; d++) {
+          uint32_t word = 0;
+          for (int half = 0; half < 2; half++) {
+            int e = 2 * d + half;
+            int out = lane & 31, con = kslot_row(ms, lane >> 5, e);
+            int x = inverse ? out : con;
+            long ph = ((long)out * con * (N / 32) + (long)x * k1 * mult) % N;      // in units of 2 pi / N
+            double ang = (inverse ? 2.0 : -2.0) * kPi * (double)ph / (double)N;
+            double re = scale * cos(ang), im = scale * sin(ang);
+            double v = which == 0 ? re : (which == 1 ? im : -im);
+            word |= (uint32_t)to_dt(v, dtype) << (16 * half);
+          }
+          w[((ms * 3 + which) * 64 + lane) * 4 + d] = word;
+        }
+}
+
 // ctab16: [rr 8][lane 64][re(2rr) im(2rr) re(2rr+1) im(2rr+1)]
 template <class F>
 void fill_ctab16(uint8_t* dst, F fn) {
@@ -264,6 +290,18 @@ void build(HostPlan* p) {
       t.matk[k0][inv] = bl.alloc(6 * 64 * 16);
       fill_mat_pass(p->blob.data() + t.matk[k0][inv], GEO::N1, p->dtype, k0, p->R, inv != 0);
     }
+  t.fold = 0;
+#ifndef FFC_FOLD_TW
+#define FFC_FOLD_TW 0
+#endif
+  // (only in builds with the switch: 768 KB per plan; measured in round 5 and not adopted)
+  if (FFC_FOLD_TW != 0 && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32 && p->R == 1) {
+    t.fold = bl.alloc(4 * 32 * 6144);
+    for (int which4 = 0; which4 < 4; which4++)
+      for (int k1 = 0; k1 < 32; k1++)
+        fill_mat_fold(p->blob.data() + t.fold + (which4 * 32 + k1) * 6144, p->dtype, which4, k1, GEO::N,
+                      which4 == 0 ? p->s_fwd : (which4 == 3 ? p->s_inv : 1.0));
+  }
   t.total = (int)p->blob.size();
   // internal position -> natural frequency: pass k0 holds f = k0 + R * f' (f' = the inner kernel's frequency)
   p->kf_freq.resize((size_t)p->R * GEO::NT * 1024);

@@ -18,6 +18,13 @@ struct PlanTabs {      // byte offsets into the plan blob
   // frequency-sparse kernels (32-point inner digits): K-step-0 operand table of the 32-point DFT whose contraction slots hold
   // k3 = 0..3 (lane half 0) and 28..31 (lane half 1) -- the only non-zero spectrum rows of a low-pass k_f (ffc_conv_fwd_sparse)
   int mat_sp;
+  // Round 5 (build switch FFC_FOLD_TW): outer twiddle folded into per-tile inner DFT matrices, single-pass fft 32768 plans only
+  // (0 = absent).  [which 4][tile k1 32][6 x 64 x 16 bytes], same operand layout as mat[]: which 0 = forward stage a
+  // (s_fwd W_32^{n2 k2} W_N^{32 n2 k1}, factor on the contraction index n2), 1 = forward stage b (W_32^{n3 k3} W_N^{n3 k1}),
+  // 2 = inverse stage b (W_32^{-n3 k3} W_N^{-n3 k1}, factor on the output index n3), 3 = inverse stage a (s_inv W_32^{-n2 k2}
+  // W_N^{-32 n2 k1}): W_N^{m k1} with m = 32 n2 + n3 is the product of a factor on n2 and one on n3, and each of them sits on an index
+  // that an inner stage contracts (forward) or produces (inverse) -- no elementwise outer twiddle is left (ffc_body.h tile_fwd / tile_inv)
+  int fold;
   int total;
 };
 

@@ -448,6 +448,12 @@ template <class GEO, int DT> struct BwdRun {
             }
           }
           if constexpr (GEO::OUTER) {
+            // (the library's launcher runs the saved-spectra form as its own instantiation, ZM = 1: ffc_k_bwdz.hip)
+            if (d.zin) {
+              if ((GEO::N1 / 2) * GEO::Mi >= d.c.L) Modes<SimBO, GEO, DT>::template bwd<true, false, true, 1>(d, h, c, h * d.c.nchunk + c);
+              else Modes<SimBO, GEO, DT>::template bwd<false, false, true, 1>(d, h, c, h * d.c.nchunk + c);
+              return;
+            }
             if ((GEO::N1 / 2) * GEO::Mi >= d.c.L) { Modes<SimBO, GEO, DT>::template bwd<true>(d, h, c, h * d.c.nchunk + c); return; }
           }
           Modes<SimBO, GEO, DT>::bwd(d, h, c, h * d.c.nchunk + c);

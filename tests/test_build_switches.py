@@ -66,3 +66,45 @@ def test_build_switches_do_not_change_a_bit():
     assert len(base) == len(CASES) == len(alt)
     for a, b in zip(base, alt):
         assert a == b, (a, b)
+
+
+# ---------------------------------------------------------------- FFC_FOLD_TW (round 5; measured, not adopted: DESIGN.md section 8)
+_FOLD_SCRIPT = r'''
+import sys, numpy as np
+sys.path[:0] = [%r, %r, %r]
+import simlib as S
+from oracle import ref_fft_conv as O
+rel = lambda a, b: np.linalg.norm(np.asarray(a).astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30)
+q = lambda x, dt: S.from_bits(S.to_bits(x, dt), dt).astype(np.float64)
+for (N, L, B, H, gated, dt) in [(32768, 16384, 3, 1, False, 0), (32768, 32768, 2, 1, False, 0), (32768, 9000, 2, 1, True, 0), (32768, 16384, 2, 1, True, 1)]:
+    rng = np.random.default_rng(N + L + B)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None; post = S.to_bits(g2, dt) if gated else None
+    y, du, dpre, dpost, ws = S.sim_fwd_bwd_z(N, dt, S.to_bits(u, dt), S.to_bits(d, dt), kf, pre, post, 1, flags=0)
+    nt, _, _, _ = S.plan_info(N, dt)
+    dk = np.full((H, L), np.nan, np.float32)
+    assert S.lib().ffcsim_kernel_ifft_grad(N, dt, S.p(ws), ws.size // (H * nt * 2048), H, L, S.p(dk)) == 0
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype=("bf16", "fp16")[dt]) if gated else O.ref_fft_conv(q(u, dt), k, N)
+    r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), k, q(d, dt), N)
+    print(rel(S.from_bits(y, dt), ref), rel(S.from_bits(du, dt), r[0]), rel(dk, r[1]), dt, flush=True)
+'''
+
+
+def test_folded_outer_twiddle_variant_matches_the_oracle():
+    """-DFFC_FOLD_TW=1: the outer twiddle folded into per-tile inner DFT matrices (forward kernels + the saved-spectra backward of
+    fft 32768).  The variant simulator takes ~6 min to compile, so this runs only where it has been built
+    (g++ -O0 -std=c++17 -fPIC -shared -pthread -DFFC_FOLD_TW=1 -o lib/variants/sim_fold/libffcsim2.so csrc/ffc_sim.cpp csrc/ffc_plan.cpp)."""
+    so = os.path.join(PKG, "lib", "variants", "sim_fold", "libffcsim2.so")
+    csrc = os.path.join(PKG, "csrc")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(csrc, f)) for f in ("ffc_body.h", "ffc_modes.h", "ffc_plan.cpp")):
+        pytest.skip("variant simulator not built (or older than the kernel sources)")
+    env = dict(os.environ, FFC_SIM_LIB=so)
+    r = subprocess.run([sys.executable, "-c", _FOLD_SCRIPT % (HERE, PKG, os.path.dirname(HERE))], env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(rows) == 4
+    for y, du, dk, dt in rows:
+        tol = 1.2e-2 if dt == "0" else 1.5e-3
+        assert float(y) < tol and float(du) < tol and float(dk) < 1.8e-2, (y, du, dk, dt)
