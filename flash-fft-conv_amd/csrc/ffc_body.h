@@ -175,6 +175,13 @@ struct Body {
   // the -Fi product is Fi times the negated imaginary operand (sign bits flipped: 4 v_xor per K-step)
   struct Mat2 { W4 w[2][2]; };
   static FFC_FN void load_mat2_issue(Mat2& m, const uint8_t* p, i32 lane) {
+#if defined(FFC_KO) && (FFC_KO & 2048)
+    // knock-out timing experiment (results wrong): no L2 traffic for the folded matrices -- every "load" is the lane id, so that the
+    // folded kernels' instruction stream can be timed without the cost of fetching the tables
+    { const u32 z = B::as_u32(B::i2f(lane));
+      for (int ms = 0; ms < 2; ms++) for (int f = 0; f < 2; f++) m.w[ms][f] = B::w4(z, z, z, z);
+      (void)p; return; }
+#endif
 #pragma unroll
     for (int ms = 0; ms < 2; ms++)
 #pragma unroll
