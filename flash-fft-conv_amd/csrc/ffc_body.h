@@ -300,9 +300,16 @@ struct Body {
       apply8(re, im, 1, tr, ti);
     }
   }
+#ifndef FFC_PK_GATE
+#define FFC_PK_GATE 1
+#endif
   // dtype pair (x) dtype pair, rounded back to dtype (the reference multiplies gates in the
   // activation dtype: kernels_bf16/monarch_cuda_32_32_32_kernel_bf16.h:409-429, 613-634).
   static FFC_FN u32 mul2(u32 a, u32 g) {
+    // fp16: one v_pk_mul_f16 (round 5).  The product of two fp16 values is exact in fp32, so "fp32 product rounded once" IS the native
+    // fp16 multiply -- bit for bit what the widening path below computes (2 x 2 conversions, 2 multiplies, 1 pack), and what the
+    // reference's __hmul2 does.  bf16 has no packed multiply on gfx950.  FFC_PK_GATE=0: the widening path for both dtypes (A/B builds)
+    if constexpr (DT == DT_F16 && FFC_PK_GATE != 0) return B::pk_mul_f16(a, g);
     f32 lo = B::template unpack_lo<DT>(a) * B::template unpack_lo<DT>(g);
     f32 hi = B::template unpack_hi<DT>(a) * B::template unpack_hi<DT>(g);
     return B::template pack<DT>(lo, hi);

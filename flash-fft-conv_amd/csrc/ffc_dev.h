@@ -283,6 +283,9 @@ struct DevB {
     if (DT == DT_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
   }
+  static FFC_FN u32 pk_mul_f16(u32 a, u32 b) {      // v_pk_mul_f16
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, b));
+  }
   template <int DT>
   static FFC_FN f32 unpack_lo(u32 a) {
     if (DT == DT_BF16) return __builtin_bit_cast(float, a << 16);

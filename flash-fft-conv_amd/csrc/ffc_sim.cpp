@@ -297,6 +297,16 @@ struct SimB {
     for (int i = 0; i < 64; i++) r.v[i] = f32_to_dt(DT, lo.v[i]) | ((uint32_t)f32_to_dt(DT, hi.v[i]) << 16);
     return r;
   }
+  // v_pk_mul_f16: the exact fp32 product of two fp16 values rounded once to fp16 (= the native fp16 multiply)
+  static u32 pk_mul_f16(const u32& a, const u32& b) {
+    u32 r;
+    for (int i = 0; i < 64; i++) {
+      float lo = f16_to_f32((uint16_t)a.v[i]) * f16_to_f32((uint16_t)b.v[i]);
+      float hi = f16_to_f32((uint16_t)(a.v[i] >> 16)) * f16_to_f32((uint16_t)(b.v[i] >> 16));
+      r.v[i] = f32_to_f16(lo) | ((uint32_t)f32_to_f16(hi) << 16);
+    }
+    return r;
+  }
   template <int DT> static f32 unpack_lo(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)a.v[i]); return r; }
   template <int DT> static f32 unpack_hi(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)(a.v[i] >> 16)); return r; }
 };

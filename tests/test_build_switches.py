@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(os.path.dirname(HERE), "flash-fft-conv_amd")
 # round 5: FFC_OUTER_QUAD = 0 is the tile-pair form of phases A / C (4-byte LDS accesses), FFC_RP_FASTK = 0 the multi-pass backward with the
 # run-time access-width switch in every row access (the default launches a 16-byte-only instantiation on aligned tensors)
-ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0"]
+# FFC_PK_GATE = 0: fp16 gate multiplies through fp32 (the packed fp16 multiply rounds the exact product once: the same bits)
+ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0", "-DFFC_PK_GATE=0"]
 
 
 def _alt_sim():
