@@ -94,6 +94,9 @@ def compact(out):
     # tables: [fwd_ms, bwd_ms] per row, keyed by L (sweep) / config name; README table: speed-up over the published H100 time
     if out.get("sweep"):
         c["sweep_fwd_bwd_ms"] = {str(r["L"]): [r["fwd_ms"], r["bwd_ms"]] for r in out["sweep"]}
+        gs = {str(r["L"]): r["graph_step_ms"] for r in out["sweep"] if r.get("graph_step_ms") is not None}
+        if gs:      # short rows: fwd+bwd as one HIP graph (the eager backward is host-bound there)
+            c["sweep_graph_step_ms"] = gs
     if out.get("sweep_gated"):
         c["sweep_gated_fwd_bwd_ms"] = {str(r["L"]): [r["fwd_ms"], r["bwd_ms"]] for r in out["sweep_gated"]}
     if out.get("configs"):
@@ -478,7 +481,7 @@ def main():
         torch.cuda.empty_cache()
         from benchmarks import sweep as SW
         keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "fwd_ms_min", "bwd_ms_min", "fwd_infer_ms", "timing", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
-                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes")
+                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes", "graph_step_ms")
         out["configs"] = [{kk: r[kk] for kk in keep if kk in r} for r in SW.config_rows()]
         # peak memory of the headline config (module level: save_spectrum on / off, inference forward, torch.fft form)
         out["peak_mem_bytes"] = out["configs"][0].get("peak_mem_bytes")

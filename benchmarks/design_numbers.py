@@ -42,6 +42,11 @@ for r in d["configs"] + d["sweep"] + d.get("sweep_gated", []):
                f"{'%.4g / %.4g' % old if old and old[0] else ''} | {mb(p.get('fwd_bwd_save_spectrum'))} / {mb(p.get('fwd_bwd_recompute'))} / {mb(p.get('fwd_bwd_torch_fft'))} |")
 out.append("")
 out.append("(* fewer heads run, rescaled to H = 768, as the reference's own benchmark does; the memory columns are the heads actually run.)")
+gs = [r for r in d["sweep"] + d.get("sweep_gated", []) if r.get("graph_step_ms") is not None]
+if gs:
+    out.append("")
+    out.append("Short rows as ONE HIP graph (`FlashFFTConv.graphed_step`: forward + backward + every gradient per replay, HIP events) — at B16 H768 these rows are bound by their kernels, so the graph only takes the host out of the picture (it matters on boxes with a slow host and for smaller batches, `profiles/r05_graph_step.txt`): "
+               + ", ".join(f"{r['row']} **{r['graph_step_ms']:.4g} ms** per step (eager fwd + bwd {r['fwd_ms'] + r['bwd_ms']:.4g})" for r in gs) + ".")
 out.append("")
 t = d["readme_table"]
 out.append("The reference's published table (README.md:224-230: gated forward, fp16, L = N, scaled to B = 64 × H = 768, 1 × H100-SXM) at the same shapes: N = "

@@ -114,6 +114,13 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
         y.backward(dout, retain_graph=True)
     (t_b, t_b_min) = ev_time(bwd, iters)
     del y
+    # short sequences: the eager backward above is bound by the host side of autograd, not by its kernels; the
+    # whole fwd+bwd step as ONE HIP graph (FlashFFTConv.graphed_step) is what the GPU actually needs for it
+    t_g = None
+    if N <= 8192:
+        step = mod.graphed_step(u, k, dout, *g)
+        (t_g, _) = ev_time(step.replay, iters)
+        del step
     pm = peak_mem_row(mod, u, k, g, dout, N)
     scale = H / Hrun
     t_f, t_b, t_fi, t_f_min, t_b_min = t_f * scale, t_b * scale, t_fi * scale, t_f_min * scale, t_b_min * scale
@@ -131,7 +138,7 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
                       "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
                       "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9),
                       "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4),
-                      "peak_mem_bytes": pm})
+                      "peak_mem_bytes": pm, **({"graph_step_ms": round(t_g * scale, 4)} if t_g is not None else {})})
 
 
 def conv1d_row():
