@@ -1534,15 +1534,13 @@ struct Body {
   // forward half: E tile -> Z = s_fwd*FFT in layout [V'=(sV,k3) regs][U'=(sU,k2) lanes]
   // TWR: inner twiddle table resident in registers (R.tw); false -> re-read from LDS at each use (saves 32
   // VGPRs in the register-heavy backward kernels)
-  // FFC_FOLD_TW (round 5, build switch): the outer twiddle W_N^{m k1}, m = 32 n2 + n3, is the product of a factor on n2 and one on n3,
+  // FFC_FOLD_TW (round 5): the outer twiddle W_N^{m k1}, m = 32 n2 + n3, is the product of a factor on n2 and one on n3,
   // and each inner stage contracts (forward) resp. produces (inverse) exactly one of the two indices -- so both factors fold into
   // the stages' DFT matrices, one 6 KB operand table per (stage, tile k1) from L2 (PlanTabs::fold, 768 KB per plan), and NO elementwise
   // outer twiddle is left: no chain (v_sin / v_cos), no 16 complex multiplies per tile and direction.  s_fwd / s_inv ride in the
   // stage-a matrices.  Geo<32,32,32>, single pass.  `fold` = plan blob + PlanTabs::fold.
-#ifndef FFC_FOLD_TW
-#define FFC_FOLD_TW 0
-#endif
-  static constexpr bool CAN_FOLD = FFC_FOLD_TW != 0 && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
+  // FFC_FOLD_TW (ffc_plan.h): 1 = the forward kernels of fft 16384 (default), 2 = also fft 32768 (forward + saved-spectra backward)
+  static constexpr bool CAN_FOLD = ((FFC_FOLD_TW >= 1 && GEO::N1 == 16) || (FFC_FOLD_TW >= 2 && GEO::N1 == 32)) && GEO::N2 == 32 && GEO::N3 == 32;
   template <bool TWR = true, bool IP = false, bool FOLD = false>
   static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im, const InnerPass* ip = nullptr, const uint8_t* fold = nullptr,
                               const Mat2* fa_pre = nullptr) {
@@ -1550,8 +1548,8 @@ struct Body {
       const i32 lane = B::opaque(B::lane());
       Mat2 FA, FB;
       if (fa_pre) FA = *fa_pre;                 // requested by the caller during the previous tile (one stage of lookahead)
-      else load_mat2_issue(FA, fold + (0 * 32 + tau) * 6144, lane);
-      load_mat2_issue(FB, fold + (1 * 32 + tau) * 6144, lane);
+      else load_mat2_issue(FA, fold + (0 * GEO::NT + tau) * 6144, lane);
+      load_mat2_issue(FB, fold + (1 * GEO::NT + tau) * 6144, lane);
       Op op;
       load_tile_op(tau, op, un, R);
       re = B::a16_zero(); im = B::a16_zero();
@@ -1596,12 +1594,12 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const i32 c = lane & 31, hi = lane >> 5;
     if constexpr (FOLD) {
-      static_assert(!RP && !IP && CAN_FOLD, "folded outer twiddle: single-pass fft 32768");
+      static_assert(!RP && !IP && CAN_FOLD, "folded outer twiddle: single-pass fft 16384 / 32768");
       Mat2 GB, GA;                  // conjugation and the outer inverse factors (+ s_inv) are in the tables: plain products
       if (g_pre) { GB = g_pre[0]; GA = g_pre[1]; }      // requested by the caller behind the forward half
       else {
-        load_mat2_issue(GB, fold + (2 * 32 + tau) * 6144, lane);
-        load_mat2_issue(GA, fold + (3 * 32 + tau) * 6144, lane);
+        load_mat2_issue(GB, fold + (2 * GEO::NT + tau) * 6144, lane);
+        load_mat2_issue(GA, fold + (3 * GEO::NT + tau) * 6144, lane);
       }
       Op op;
       to_op(re, im, op);
@@ -1961,16 +1959,16 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const uint8_t* fold = a.tab + a.t.fold;
     Mat2 FAa, FAb, FBa, FBb;
-    load_mat2_issue(FAa, fold + (0 * 32 + tauA) * 6144, lane);
-    load_mat2_issue(FAb, fold + (0 * 32 + tauB) * 6144, lane);
+    load_mat2_issue(FAa, fold + (0 * GEO::NT + tauA) * 6144, lane);
+    load_mat2_issue(FAb, fold + (0 * GEO::NT + tauB) * 6144, lane);
     KfRegs kfA, kfB;
     load_kf(a, h, tauA, kfA);
     load_kf(a, h, tauB, kfB);
     Op opA, opB;
     load_tile_op(tauA, opA, un, R);
     load_tile_op(tauB, opB, un, R);
-    load_mat2_issue(FBa, fold + (1 * 32 + tauA) * 6144, lane);
-    load_mat2_issue(FBb, fold + (1 * 32 + tauB) * 6144, lane);
+    load_mat2_issue(FBa, fold + (1 * GEO::NT + tauA) * 6144, lane);
+    load_mat2_issue(FBb, fold + (1 * GEO::NT + tauB) * 6144, lane);
     A16 reA, imA, reB, imB;
     auto tw_fwd = [&](A16& re, A16& im) { if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<false>(re, im, GEO::L_TW); else cmul(re, im, R.tw); };
     auto tw_inv = [&](A16& re, A16& im) { if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<true>(re, im, GEO::L_TW); else cmul_conj(re, im, R.tw); };
@@ -1981,8 +1979,8 @@ struct Body {
     cmm2<true>(reB, imB, opB, FAb);
     tw_fwd(reA, imA); to_op(reA, imA, opA);
     Mat2 GBa, GBb;
-    load_mat2_issue(GBa, fold + (2 * 32 + tauA) * 6144, lane);
-    load_mat2_issue(GBb, fold + (2 * 32 + tauB) * 6144, lane);
+    load_mat2_issue(GBa, fold + (2 * GEO::NT + tauA) * 6144, lane);
+    load_mat2_issue(GBb, fold + (2 * GEO::NT + tauB) * 6144, lane);
     // stage b
     reA = B::a16_zero(); imA = B::a16_zero();
     cmm2<false>(reA, imA, opA, FBa);
@@ -1993,8 +1991,8 @@ struct Body {
     // (x) k_f, inverse stage b
     kf_mul<SZ>(a, kfA, reA, imA); to_op(reA, imA, opA);
     Mat2 GAa, GAb;
-    load_mat2_issue(GAa, fold + (3 * 32 + tauA) * 6144, lane);
-    load_mat2_issue(GAb, fold + (3 * 32 + tauB) * 6144, lane);
+    load_mat2_issue(GAa, fold + (3 * GEO::NT + tauA) * 6144, lane);
+    load_mat2_issue(GAb, fold + (3 * GEO::NT + tauB) * 6144, lane);
     reA = B::a16_zero(); imA = B::a16_zero();
     cmm2<true>(reA, imA, opA, GBa);
     kf_mul<SZ>(a, kfB, reB, imB); to_op(reB, imB, opB);
@@ -2021,21 +2019,21 @@ struct Body {
     const i32 lane = B::opaque(B::lane());
     const uint8_t* fold = a.tab + a.t.fold;
     Mat2 FA, FB, GB, GA;
-    load_mat2_issue(FA, fold + (0 * 32 + tau) * 6144, lane);
+    load_mat2_issue(FA, fold + (0 * GEO::NT + tau) * 6144, lane);
     KfRegs kf;
     load_kf(a, h, tau, kf);
     Op op;
     load_tile_op(tau, op, un, R);
-    load_mat2_issue(FB, fold + (1 * 32 + tau) * 6144, lane);
+    load_mat2_issue(FB, fold + (1 * GEO::NT + tau) * 6144, lane);
     A16 re, im;
     re = B::a16_zero(); im = B::a16_zero();
     cmm2<true>(re, im, op, FA);
-    load_mat2_issue(GB, fold + (2 * 32 + tau) * 6144, lane);
+    load_mat2_issue(GB, fold + (2 * GEO::NT + tau) * 6144, lane);
     if constexpr (FFC_FOLD_LDSTW != 0) cmul_lds<false>(re, im, GEO::L_TW); else cmul(re, im, R.tw);
     to_op(re, im, op);
     re = B::a16_zero(); im = B::a16_zero();
     cmm2<false>(re, im, op, FB);
-    load_mat2_issue(GA, fold + (3 * 32 + tau) * 6144, lane);
+    load_mat2_issue(GA, fold + (3 * GEO::NT + tau) * 6144, lane);
     if constexpr (SZ) z_store(zs, tau, re, im, FFC_Z_STREAM);
     kf_mul<SZ>(a, kf, re, im); to_op(re, im, op);
     re = B::a16_zero(); im = B::a16_zero();
@@ -2100,6 +2098,64 @@ struct Body {
   // in lock-step instead of two tiles of one unit.  Both tiles meet the same k_f tile and the same outer inverse twiddle
   // W_N^{-m k1}: one k_f load + unpack and one twiddle chain (4 v_sin/v_cos pairs + the chain multiplies) serve both.
   // R holds the offsets of the first unit of the group, the partner's E lies EBYTES behind it.
+  // FFC_FOLD_TW form of inner_tile2x: the two units' tiles share the tile's four folded matrices (half the matrix bytes per pair of the
+  // one-unit sizes), each requested one stage ahead
+  template <bool SZ>
+  static FFC_FN void inner_tile2x_fold(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un, uint8_t* zsA, uint8_t* zsB) {
+    static_assert(CAN_FOLD && GEO::UPW >= 2, "folded outer twiddle, two units per workgroup");
+    constexpr int DB = GEO::EBYTES;
+    const i32 lane = B::opaque(B::lane());
+    const uint8_t* fold = a.tab + a.t.fold;
+    Mat2 FA, FB, GB, GA;
+    load_mat2_issue(FA, fold + (0 * GEO::NT + tau) * 6144, lane);
+    KfRegs kf;
+    load_kf(a, h, tau, kf);
+    Op opA, opB;
+    load_tile_op(tau, opA, un, R);
+    load_tile_op(tau, opB, un, R, DB);
+    load_mat2_issue(FB, fold + (1 * GEO::NT + tau) * 6144, lane);
+    A16 reA, imA, reB, imB;
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<true>(reA, imA, opA, FA);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<true>(reB, imB, opB, FA);
+    load_mat2_issue(GB, fold + (2 * GEO::NT + tau) * 6144, lane);
+    cmul(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<false>(reA, imA, opA, FB);
+    cmul(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<false>(reB, imB, opB, FB);
+    load_mat2_issue(GA, fold + (3 * GEO::NT + tau) * 6144, lane);
+    if constexpr (SZ) { z_store(zsA, tau, reA, imA, FFC_Z_STREAM); z_store(zsB, tau, reB, imB, FFC_Z_STREAM); }
+    {
+      CT16 k;
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) {
+        u32 wv[4] = {kf.v[rq].x, kf.v[rq].y, kf.v[rq].z, kf.v[rq].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          k.re[4 * rq + q] = B::template unpack_lo<DT>(wv[q]);
+          k.im[4 * rq + q] = B::template unpack_hi<DT>(wv[q]);
+        }
+      }
+      if constexpr (!SZ) k.im = B::a16_scale(k.im, a.conj_kf ? -1.0f : 1.0f);
+      cmul(reA, imA, k); to_op(reA, imA, opA);
+      reA = B::a16_zero(); imA = B::a16_zero();
+      cmm2<true>(reA, imA, opA, GB);
+      cmul(reB, imB, k); to_op(reB, imB, opB);
+      reB = B::a16_zero(); imB = B::a16_zero();
+      cmm2<true>(reB, imB, opB, GB);
+    }
+    cmul_conj(reA, imA, R.tw); to_op(reA, imA, opA);
+    reA = B::a16_zero(); imA = B::a16_zero();
+    cmm2<true>(reA, imA, opA, GA);
+    cmul_conj(reB, imB, R.tw); to_op(reB, imB, opB);
+    reB = B::a16_zero(); imB = B::a16_zero();
+    cmm2<true>(reB, imB, opB, GA);
+    tile_store(tau, R, reA, imA);
+    tile_store(tau, R, reB, imB, DB);
+  }
   template <bool SZ = false>
   static FFC_FN void inner_tile2x(const ConvArgs& a, int h, int tau, const InnerRegs& R, Unit un, uint8_t* zsA = nullptr, uint8_t* zsB = nullptr) {
     static_assert(GEO::N3 == GEO::N2 && GEO::OUTER && GEO::UPW >= 2, "inner_tile2x: two units per workgroup");
@@ -2277,10 +2333,11 @@ struct Body {
 #pragma unroll 1
             for (int tt = 0; tt < 2; tt++) {
               if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
-              inner_tile2x<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
+              if constexpr (FOLDF) inner_tile2x_fold<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
+              else inner_tile2x<SZ>(a, hk, wl * 2 + tt, R, ua, zA, zA + (int64_t)GEO::N * 4);
             }
           } else {
-            inner_tile2<false, SZ>(a, hk, wl * 2, R, ua, Pass(), zA);
+            inner_tile2<false, SZ, FOLDF, HALF>(a, hk, wl * 2, R, ua, Pass(), zA);
           }
         }
       } else if (act) {

@@ -795,7 +795,7 @@ struct Modes : Body<B, GEO, DT> {
     constexpr bool PF = FFC_Z_PREFETCH != 0 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW) && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
     // folded outer twiddle (Body::tile_fwd / tile_inv <.., FOLD>): the saved-spectra backward of single-pass fft 32768, whose phase A ran
     // without the twiddle (Modes::bwd)
-    constexpr bool FOLD = BD::CAN_FOLD && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW);
+    constexpr bool FOLD = BD::CAN_FOLD && GEO::N1 == 32 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW);
     const uint8_t* fold = FOLD ? a.tab + a.t.fold : nullptr;
     typename BD::KfRegs zv;
     if constexpr (PF) z_load(zs, un.wq * GEO::TPW, zv, z_stream || (a.flags & 4) != 0);
@@ -841,8 +841,8 @@ struct Modes : Body<B, GEO, DT> {
         typename BD::Mat2 g[2];
         if constexpr (FOLD) {        // the inverse half's matrices, in flight under the accumulation and the k_f product
           const i32 lane = B::opaque(B::lane());
-          BD::load_mat2_issue(g[0], fold + (2 * 32 + tau) * 6144, lane);
-          BD::load_mat2_issue(g[1], fold + (3 * 32 + tau) * 6144, lane);
+          BD::load_mat2_issue(g[0], fold + (2 * GEO::NT + tau) * 6144, lane);
+          BD::load_mat2_issue(g[1], fold + (3 * GEO::NT + tau) * 6144, lane);
         }
         kf_conj_mul(kf, re, im);
         if constexpr (FOLD) {        // next tile's first matrix (clamped on the last iteration)
@@ -1089,7 +1089,7 @@ struct Modes : Body<B, GEO, DT> {
       // DESIGN.md section 7)
       const bool have_z = ZM < 0 ? d.zin != nullptr : ZM == 1;
       // FFC_FOLD_TW: the saved-spectra kernel of single-pass fft 32768 runs phase A of dout without the outer twiddle (bwd_tiles folds it)
-      constexpr bool FOLDZ = BD::CAN_FOLD && ZM == 1 && !RP && (WREG >= GEO::TPW);
+      constexpr bool FOLDZ = BD::CAN_FOLD && GEO::N1 == 32 && ZM == 1 && !RP && (WREG >= GEO::TPW);
       // input rows of dout by LDS-DMA into the dead half of the exchange buffer (Body::rows_dma): saved-spectra form of the
       // HALF kernels with a 32-point outer digit, plain rows (no gate multiply / side product on the way in), 16-byte-aligned
       // tensors; tuning flag 8 (FFC_FLAGS) keeps the register path for A/B runs

@@ -291,15 +291,12 @@ void build(HostPlan* p) {
       fill_mat_pass(p->blob.data() + t.matk[k0][inv], GEO::N1, p->dtype, k0, p->R, inv != 0);
     }
   t.fold = 0;
-#ifndef FFC_FOLD_TW
-#define FFC_FOLD_TW 0
-#endif
-  // (only in builds with the switch: 768 KB per plan; measured in round 5 and not adopted)
-  if (FFC_FOLD_TW != 0 && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32 && p->R == 1) {
-    t.fold = bl.alloc(4 * 32 * 6144);
+  // (fft 16384: 384 KB per plan, product; fft 32768: 768 KB, only in builds with FFC_FOLD_TW=2 -- measured and not adopted)
+  if (((FFC_FOLD_TW >= 1 && GEO::N1 == 16) || (FFC_FOLD_TW >= 2 && GEO::N1 == 32)) && GEO::N2 == 32 && GEO::N3 == 32 && p->R == 1) {
+    t.fold = bl.alloc(4 * GEO::NT * 6144);
     for (int which4 = 0; which4 < 4; which4++)
-      for (int k1 = 0; k1 < 32; k1++)
-        fill_mat_fold(p->blob.data() + t.fold + (which4 * 32 + k1) * 6144, p->dtype, which4, k1, GEO::N,
+      for (int k1 = 0; k1 < GEO::NT; k1++)
+        fill_mat_fold(p->blob.data() + t.fold + (which4 * GEO::NT + k1) * 6144, p->dtype, which4, k1, GEO::N,
                       which4 == 0 ? p->s_fwd : (which4 == 3 ? p->s_inv : 1.0));
   }
   t.total = (int)p->blob.size();

@@ -5,6 +5,13 @@
 #include <stdint.h>
 #include <vector>
 
+// Outer twiddle folded into per-(stage, tile) inner DFT matrices (ffc_body.h tile_fwd; PlanTabs::fold).  0: off; 1 (default): the forward
+// kernels of fft 16384, where two pairs share a tile's matrices (measured -6 .. -8 %, profiles/r05_ab_fold_twiddle.txt); 2: also fft 32768
+// (forward + saved-spectra backward; measured +-1 %: the L2 fetches of the matrices cost what the removed instructions save)
+#ifndef FFC_FOLD_TW
+#define FFC_FOLD_TW 1
+#endif
+
 namespace ffc {
 
 struct PlanTabs {      // byte offsets into the plan blob

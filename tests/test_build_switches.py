@@ -94,9 +94,9 @@ for (N, L, B, H, gated, dt) in [(32768, 16384, 3, 1, False, 0), (32768, 32768, 2
 
 
 def test_folded_outer_twiddle_variant_matches_the_oracle():
-    """-DFFC_FOLD_TW=1: the outer twiddle folded into per-tile inner DFT matrices (forward kernels + the saved-spectra backward of
-    fft 32768).  The variant simulator takes ~6 min to compile, so this runs only where it has been built
-    (g++ -O0 -std=c++17 -fPIC -shared -pthread -DFFC_FOLD_TW=1 -o lib/variants/sim_fold/libffcsim2.so csrc/ffc_sim.cpp csrc/ffc_plan.cpp)."""
+    """-DFFC_FOLD_TW=2: the outer twiddle folded into per-tile inner DFT matrices also at fft 32768 (forward kernels + the saved-spectra backward;
+    the product folds the forward of fft 16384 only).  The variant simulator takes ~6 min to compile, so this runs only where it has been built
+    (g++ -O0 -std=c++17 -fPIC -shared -pthread -DFFC_FOLD_TW=2 -o lib/variants/sim_fold/libffcsim2.so csrc/ffc_sim.cpp csrc/ffc_plan.cpp)."""
     so = os.path.join(PKG, "lib", "variants", "sim_fold", "libffcsim2.so")
     csrc = os.path.join(PKG, "csrc")
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(os.path.join(csrc, f)) for f in ("ffc_body.h", "ffc_modes.h", "ffc_plan.cpp")):

@@ -171,7 +171,8 @@ def test_big_sizes_through_outer_levels(N, L, B, gated):
 @pytest.mark.parametrize("N,L,rows", [(32768, 16384, 4), (32768, 32768, 2), (16384, 8192, 4), (16384, 5000, 1)])
 def test_frequency_sparse_kernel_skips_zero_rows(N, L, rows):
     """ffc_conv_fwd_sparse (kernel variant SP): with a low-pass k_f (non-zero bins |f| < rows N / 32) the compute-skipping
-    kernel returns bit for bit what the dense kernel returns on the same masked k_f, forward and conj(k_f) pass."""
+    kernel returns bit for bit what the dense kernel returns on the same masked k_f, forward and conj(k_f) pass (fft 16384: to
+    rounding, the dense kernel there folds its outer twiddle)."""
     rng = np.random.default_rng(N + rows)
     dt, B, H = 0, 3, 1
     u, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(3))
@@ -188,7 +189,10 @@ def test_frequency_sparse_kernel_skips_zero_rows(N, L, rows):
             sparse = S.sim_conv_fwd(N, dt, ub, kf, S.to_bits(g1, dt), S.to_bits(g2, dt), conj=conj)
         finally:
             S.lib().ffcsim_set_sparse(0)
-        assert np.array_equal(dense, sparse), f"conj={conj}: {int((dense != sparse).sum())} elements differ"
+        if N == 16384:      # round 5: the dense forward of fft 16384 folds its outer twiddle into the stage matrices, the sparse variant keeps the chains
+            assert rel(S.from_bits(sparse, dt), S.from_bits(dense, dt).astype(np.float64)) < 1e-2
+        else:
+            assert np.array_equal(dense, sparse), f"conj={conj}: {int((dense != sparse).sum())} elements differ"
     yref = np.fft.ifft(np.fft.fft(q(u, dt).astype(np.float64) * q(g1, dt), n=N) * kfn[None], n=N).real[..., :L] * q(g2, dt)
     S.lib().ffcsim_set_sparse(rows)
     try:
@@ -360,7 +364,9 @@ def test_saved_spectrum_backward_and_dma_rows(N, L, B, H, nch, gated, dt):
     nt, _, _, _ = S.plan_info(N, dt)
     dk = np.full((H, L), np.nan, np.float32)
     assert S.lib().ffcsim_kernel_ifft_grad(N, dt, S.p(ws), ws.size // (H * nt * 2048), H, L, S.p(dk)) == 0
-    assert rel(dk, dk0.astype(np.float64)) < 3e-3
+    # fft 16384: the spectrum-saving forward folds its outer twiddle into the tile matrices, the recomputing backward does not -- the two
+    # bf16 spectra differ by a rounding of the matrix entries as well (same gate as tests/test_spectrum_gpu.py)
+    assert rel(dk, dk0.astype(np.float64)) < (1.2e-2 if N == 16384 else 3e-3)
     r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), k, q(d, dt), N)
     assert rel(S.from_bits(du, dt), r[0]) < TOL[dt] and rel(dk, r[1]) < 1.5 * TOL[0]
     if gated:

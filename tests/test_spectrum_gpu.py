@@ -81,7 +81,13 @@ def test_saved_spectrum_equals_recompute(N, gated, dtype):
             # same spectrum up to the last bit of its rounding to the plan dtype (the fp32 schedule of the two kernels differs):
             # outputs that are rounded once more (dpostgate) move by single steps of the dtype
             step = 1e-2 if dtype == torch.bfloat16 else 2e-3
-            assert rel(dk1, dk0) < 2e-3, f"{tag}: dk rel {rel(dk1, dk0):.2e}"
+            dk_gate = 2e-3
+            if N == 16384:
+                # round 5: the FORWARD of fft 16384 folds the outer twiddle into its stage matrices while the
+                # recomputing backward transforms u with the chains: the saved spectrum and the recomputed one are two roundings of the
+                # same values (each ~7e-3 / 8e-4 from the oracle), no longer the same arithmetic
+                dk_gate, step = (1.2e-2, 2e-2) if dtype == torch.bfloat16 else (4e-3, 4e-3)
+            assert rel(dk1, dk0) < dk_gate, f"{tag}: dk rel {rel(dk1, dk0):.2e}"
             if gated:
                 assert torch.equal(o0[1], o1[1]), f"{tag}: dpregate"
                 assert rel(o1[2], o0[2]) < step, f"{tag}: dpostgate rel {rel(o1[2], o0[2]):.2e}"
