@@ -101,6 +101,10 @@ def compact(out):
         c["sweep_gated_fwd_bwd_ms"] = {str(r["L"]): [r["fwd_ms"], r["bwd_ms"]] for r in out["sweep_gated"]}
     if out.get("configs"):
         c["configs_fwd_bwd_ms"] = {r["row"].split(" ")[0]: [r["fwd_ms"], r["bwd_ms"]] for r in out["configs"]}
+        # rows whose module ran a smaller fft size than it was built for (FlashFFTConv._fit_seqlen: cfg4's rows fit 2097152 points)
+        fr = {r["row"].split(" ")[0]: r["fft_run"] for r in out["configs"] if r.get("fft_run") not in (None, r.get("fft"))}
+        if fr:
+            c["configs_fft_run"] = fr
     if out.get("readme_table"):
         c["readme_x_h100"] = {str(r["fft"]): r["speedup_vs_h100_published"] for r in out["readme_table"]}
         if all("bwd_ms_scaled" in r for r in out["readme_table"]):

@@ -138,6 +138,8 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
                       "tflops_fft_equiv": round(rows * (fft_f + fft_b) / ((t_f + t_b) * 1e-3) / 1e12, 2),
                       "fwd_alg_GBs": round(alg_f / (t_f * 1e-3) / 1e9), "bwd_alg_GBs": round(alg_b / (t_b * 1e-3) / 1e9),
                       "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4),
+                      # fft size the module ran: the smallest one that holds the rows' linear convolution (FlashFFTConv._fit_seqlen)
+                      "fft_run": mod._fit_seqlen(L, L),
                       "peak_mem_bytes": pm, **({"graph_step_ms": round(t_g * scale, 4)} if t_g is not None else {})})
 
 

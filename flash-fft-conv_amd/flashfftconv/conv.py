@@ -25,6 +25,8 @@ FUSED_SEQLENS = (256, 512, 1024, 4096, 8192, 16384, 32768)
 # where the HBM-level form measured 16.5.  FFC_MULTIPASS="2048,65536" etc. selects other routings for A/B runs.
 import os as _os
 MULTIPASS_SEQLENS = tuple(int(x) for x in _os.environ.get("FFC_MULTIPASS", "2048,65536,131072").split(",") if x.strip())
+# FlashFFTConv._fit_seqlen: run the smallest fft size that still holds the linear convolution of the rows handed in (fft sizes > 32768)
+_FIT_FFT = _os.environ.get("FFC_FIT_FFT", "1") != "0"
 _ROUTE_BY_LENGTH = _os.environ.get("FFC_ROUTE_BY_LENGTH", "1") != "0"      # fft 131072: HBM-level form for rows longer than N/2 (FlashFFTConv._route_big)
 # fft size 2048 has no 16/32-digit factorisation of its own.  By default it runs as 2 passes of the 1024 kernel
 # (MULTIPASS_SEQLENS below); the round-1 form, kept for A/B runs (FFC_MULTIPASS without 2048): the 4096 plan with k periodised,
@@ -737,6 +739,34 @@ class FlashFFTConv(torch.nn.Module):
         # "always" (FFC_SAVE_SPECTRUM=always): whenever the allocation succeeds; False: never (the reference's footprint)
         _sv = _os.environ.get("FFC_SAVE_SPECTRUM", "1")
         self.save_spectrum = False if _sv == "0" else ("always" if _sv == "always" else True)
+        # rows much shorter than the fft size run on the smallest fft size that holds their linear convolution (_fit_seqlen);
+        # False (or FFC_FIT_FFT=0) always runs `seqlen` points
+        self.fit_fft = True
+        self._fitted = {}
+
+    def _fit_seqlen(self, Lu, Lk):
+        """The fft size a call with rows of Lu (u, gates, output) and Lk (k) samples runs on.  While Lu + Lk - 1 <= n the n-point
+        circular convolution does not wrap: its first Lu outputs, and du / dk of them, are the LINEAR convolution's -- the same numbers
+        for every such n, `seqlen` included (one rounding stage fewer per halving).  A module built for the longest sequence of a
+        model (the reference's callers fix fft_size = 2 * l_max at construction, examples/hyena-dna) and called with shorter rows, or
+        BASELINE config 4 (fft 4194304 around L = 1048576: 2097152 points hold it), therefore runs the smallest supported size
+        n >= Lu + Lk - 1.  Only for seqlen > 32768, where a halving saves a kernel pass or an HBM level (below that the fused kernel's
+        implicit zero padding already skips the row traffic), and not for the frequency-sparse modules (their masks are defined on the
+        seqlen-point spectrum)."""
+        n = self.seqlen
+        if not (_FIT_FFT and self.fit_fft) or self._kf_keep is not None or n <= 32768:
+            return n
+        need = max(Lu + Lk - 1, 1)
+        while n > 256 and n // 2 >= need:
+            n //= 2
+        return n
+
+    def _fitted_module(self, n):
+        m = self._fitted.get(n)
+        if m is None:
+            m = self._fitted[n] = FlashFFTConv(n, dtype=self.dtype, use_32_butterfly=self.use_32_butterfly)
+        m.training, m.save_spectrum, m.cache_kf, m.fit_fft = self.training, self.save_spectrum, self.cache_kf, False
+        return m
 
     def graphed_step(self, u, k, dout, pregate=None, postgate=None, warmup=3):
         """forward + backward of this module captured into ONE HIP graph on static copies of the given tensors
@@ -784,4 +814,8 @@ class FlashFFTConv(torch.nn.Module):
     def forward(self, u, k, pregate=None, postgate=None):
         if pregate is not None or postgate is not None:
             assert pregate is not None and postgate is not None
+        if self.seqlen > 32768 and torch.is_tensor(u) and torch.is_tensor(k) and u.dim() == 3 and k.dim() == 2:
+            n = self._fit_seqlen(u.shape[-1], k.shape[-1])
+            if n != self.seqlen:
+                return self._fitted_module(n)(u, k, pregate, postgate)
         return _apply_noting_grad_mode(_FlashFFTConvFn, u, k, self, pregate, postgate)

@@ -233,6 +233,42 @@ def _chunked_reference(u, k, pre, post, dout, N, hc):
     return cat(outs, 1), [cat(grads[0], 1), cat(grads[1], 0)] + [cat(x, 1) for x in grads[2:]]
 
 
+@pytest.mark.parametrize("N,dtype,B,H,L,Lk,gated,n_run", [(65536, torch.bfloat16, 3, 4, 300, 40, False, 512),
+                                                          (131072, torch.float16, 2, 8, 16384, 16384, True, 32768),
+                                                          (131072, torch.bfloat16, 2, 4, 30000, 2000, False, 32768),
+                                                          (1048576, torch.bfloat16, 2, 2, 100000, 100000, True, 262144),
+                                                          (4194304, torch.bfloat16, 1, 2, 1048576, 1048576, False, 2097152)])
+def test_fft_size_fitted_to_the_rows(N, dtype, B, H, L, Lk, gated, n_run):
+    """round 5, FlashFFTConv._fit_seqlen: a module above the single-launch sizes handed rows whose linear convolution fits a smaller fft
+    size runs that size (BASELINE config 4: fft 4194304 around L = 1048576 runs 2097152 points).  Same numbers as the seqlen-point
+    run of the same module (fit_fft = False -- which also keeps the L <= N/4 one-level form of fft 4194304 under test) and as the
+    seqlen-point torch.fft oracle, forward and every gradient."""
+    from flashfftconv import FlashFFTConv
+    torch.manual_seed(N + L)
+    mk = lambda: torch.randn(B, H, L, device="cuda").to(dtype)
+    u, dout = mk(), mk()
+    k = torch.randn(H, Lk, device="cuda") * 0.05
+    gates = (mk(), mk()) if gated else ()
+    conv = FlashFFTConv(N, dtype=dtype).to("cuda")
+    assert conv._fit_seqlen(L, Lk) == n_run
+    res = []
+    for fit in (True, False):
+        conv.fit_fft = fit
+        leaves = [t.clone().requires_grad_(True) for t in (u, k) + gates]
+        y = conv(*leaves)
+        res.append([y.detach()] + list(torch.autograd.grad(y, leaves, dout)))
+    assert set(conv._fitted) == {n_run}
+    ref, gref = _chunked_reference(u, k, gates[0] if gated else None, gates[1] if gated else None, dout, N, 4)
+    want = [ref] + gref
+    tol = REL[dtype] * (1.5 if gated else 1.0)
+    for nm, a, b, w in zip(("out", "du", "dk", "dpregate", "dpostgate"), res[0], res[1], want):
+        assert a.shape == w.shape and a.dtype == b.dtype
+        t = max(tol, 1e-2) if nm == "dk" else tol
+        assert rel(a, w) < t, f"fitted {nm} {rel(a, w):.3e}"
+        assert rel(b, w) < t, f"seqlen-point {nm} {rel(b, w):.3e}"
+        assert rel(a, b) < t, f"fitted against seqlen-point {nm} {rel(a, b):.3e}"
+
+
 @pytest.mark.parametrize("name,N,B,H,L,gated", [("cfg2", 32768, 16, 768, 16384, False), ("cfg3", 16384, 8, 1024, 8192, True),
                                                 ("cfg4", 4194304, 1, 16, 1048576, False)])
 def test_baseline_configs_exact(name, N, B, H, L, gated):

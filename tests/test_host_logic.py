@@ -140,3 +140,53 @@ def test_fft_131072_route_is_shared_by_the_wrappers():
     assert not m._big and not m._route_big(65536) and m._route_big(65537)
     assert "_route_big" in inspect.getsource(sharding.BatchShardedFFTConv.forward)
     assert "_route_big" in inspect.getsource(hyena.gated_conv_from_slices)
+
+
+def test_fft_size_fits_the_rows():
+    """FlashFFTConv._fit_seqlen: modules above the single-launch sizes run the smallest fft size that holds the linear convolution of
+    the rows they are handed; full-size calls, the fused sizes and the frequency-sparse modules keep their size."""
+    from flashfftconv import FlashFFTConv
+    m = FlashFFTConv(4194304, dtype=torch.bfloat16)
+    assert m._fit_seqlen(1048576, 1048576) == 2097152            # BASELINE config 4
+    assert m._fit_seqlen(1048576, 1048577) == 2097152 and m._fit_seqlen(1048576, 1048578) == 4194304
+    assert m._fit_seqlen(2097152, 2097152) == 4194304 and m._fit_seqlen(4194304, 4194304) == 4194304
+    assert m._fit_seqlen(1000, 24) == 1024 and m._fit_seqlen(1, 1) == 256
+    assert FlashFFTConv(131072, dtype=torch.float16)._fit_seqlen(16384, 16384) == 32768
+    assert FlashFFTConv(65536, dtype=torch.float16)._fit_seqlen(32768, 32768) == 65536
+    assert FlashFFTConv(32768, dtype=torch.float16)._fit_seqlen(100, 100) == 32768      # fused sizes: implicit padding already
+    m.fit_fft = False
+    assert m._fit_seqlen(1000, 24) == 4194304
+    m.fit_fft, m._kf_keep = True, 100
+    assert m._fit_seqlen(1000, 24) == 4194304                    # frequency-sparse: the mask lives on the seqlen-point spectrum
+    m._kf_keep = None
+    # the fitted module follows the caller's mode switches and never fits again
+    m.eval(); m.save_spectrum = False; m.cache_kf = True
+    s = m._fitted_module(1024)
+    assert s is m._fitted_module(1024) and s.seqlen == 1024 and s.dtype == m.dtype
+    assert (s.training, s.save_spectrum, s.cache_kf, s.fit_fft) == (False, False, True, False)
+    assert list(m.state_dict()) == [] and list(m.children()) == []
+    import copy, pickle
+    assert copy.deepcopy(m)._fitted[1024].seqlen == 1024 and pickle.loads(pickle.dumps(m)).seqlen == 4194304
+
+
+@pytest.mark.parametrize("N,Lu,Lk", [(4096, 1024, 1024), (4096, 700, 1349), (2048, 1, 300), (1024, 257, 256)])
+def test_fitted_fft_size_is_the_same_convolution(N, Lu, Lk):
+    """the identity _fit_seqlen rests on, on the oracle: while Lu + Lk - 1 <= n the n-point circular convolution, its du and its dk
+    equal the N-point ones (to the rounding of the oracle's fp32 transforms); half of that size wraps"""
+    from oracle.torch_ref import ref_fft_conv
+    torch.manual_seed(N + Lu)
+    u, k, dout = torch.randn(2, 3, Lu, dtype=torch.float64), torch.randn(3, Lk, dtype=torch.float64), torch.randn(2, 3, Lu, dtype=torch.float64)
+    n = N
+    while n // 2 >= Lu + Lk - 1:
+        n //= 2
+    assert n < N
+    res = []
+    sizes = (N, n) + ((n // 2,) if n // 2 >= max(Lu, Lk) else ())
+    for size in sizes:
+        uu, kk = u.clone().requires_grad_(True), k.clone().requires_grad_(True)
+        y = ref_fft_conv(uu, kk, n=size)
+        res.append((y.detach(),) + torch.autograd.grad(y, (uu, kk), dout))
+    for a, b in zip(res[0], res[1]):
+        assert (a - b).norm() < 1e-5 * b.norm()
+    if len(res) == 3:
+        assert (res[0][0] - res[2][0]).norm() > 1e-2 * res[0][0].norm()
