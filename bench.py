@@ -485,7 +485,7 @@ def main():
         torch.cuda.empty_cache()
         from benchmarks import sweep as SW
         keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "fwd_ms_min", "bwd_ms_min", "fwd_infer_ms", "timing", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
-                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes", "graph_step_ms")
+                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes", "graph_step_ms", "fft_run")
         out["configs"] = [{kk: r[kk] for kk in keep if kk in r} for r in SW.config_rows()]
         # peak memory of the headline config (module level: save_spectrum on / off, inference forward, torch.fft form)
         out["peak_mem_bytes"] = out["configs"][0].get("peak_mem_bytes")

@@ -38,7 +38,8 @@ except Exception:
 for r in d["configs"] + d["sweep"] + d.get("sweep_gated", []):
     p = r.get("peak_mem_bytes") or {}
     old = r3.get(r["row"])
-    out.append(f"| {r['row']}{'*' if r.get('rescaled') else ''} | {r['fwd_ms']:.4g} / **{r['bwd_ms']:.4g}** | {r['fwd_hbm_frac']:.3f} / {r['bwd_hbm_frac']:.3f} | "
+    ran = f" (runs {r['fft_run']} points, §2.8)" if r.get("fft_run") not in (None, r.get("fft")) else ""
+    out.append(f"| {r['row']}{'*' if r.get('rescaled') else ''}{ran} | {r['fwd_ms']:.4g} / **{r['bwd_ms']:.4g}** | {r['fwd_hbm_frac']:.3f} / {r['bwd_hbm_frac']:.3f} | "
                f"{'%.4g / %.4g' % old if old and old[0] else ''} | {mb(p.get('fwd_bwd_save_spectrum'))} / {mb(p.get('fwd_bwd_recompute'))} / {mb(p.get('fwd_bwd_torch_fft'))} |")
 out.append("")
 out.append("(* fewer heads run, rescaled to H = 768, as the reference's own benchmark does; the memory columns are the heads actually run.)")

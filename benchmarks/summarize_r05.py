@@ -14,8 +14,9 @@ open(f"{P}/r05_bench.json", "w").write(open(f"{O}/bench.json").read().strip().sp
 open(f"{P}/r05_bench_stdout.jsonl", "w").write(open(f"{O}/bench.json").read())
 if os.path.exists(f"{O}/bench_full.json"):
     shutil.copy(f"{O}/bench_full.json", f"{P}/r05_bench_full.json")
-for d, name in (("stats", "r05_kernel_stats.csv"), ("cfg4", "r05_cfg4_kernel_stats.csv"),
-                ("cfg3", "r05_cfg3_kernel_stats.csv"), ("f1k", "r05_fft2048_kernel_stats.csv")):
+# (cfg4_s / cfg3_s: the last call's runs on the final code, benchmarks/run_r05_s.sh; cfg4 / cfg3: benchmarks/measure_r05.sh)
+for d, name in (("stats", "r05_kernel_stats.csv"), ("cfg4", "r05_cfg4_kernel_stats.csv"), ("cfg4_s", "r05_cfg4_kernel_stats.csv"),
+                ("cfg3", "r05_cfg3_kernel_stats.csv"), ("cfg3_s", "r05_cfg3_kernel_stats.csv"), ("f1k", "r05_fft2048_kernel_stats.csv")):
     f = find(d, "*kernel_stats.csv")
     if f:
         shutil.copy(f, f"{P}/{name}")
