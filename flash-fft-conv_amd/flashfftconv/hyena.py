@@ -107,6 +107,10 @@ def gated_conv_from_slices(conv, uc, k):
     if uc.dim() != 3 or uc.shape[1] % 3:
         raise RuntimeError("gated_conv_from_slices: uc must be (B, 3*D, L)")
     D, L = uc.shape[1] // 3, uc.shape[2]
+    # a model built for its longest sequence and run on a shorter one: the smallest fft size that holds the rows (FlashFFTConv._fit_seqlen)
+    n = conv._fit_seqlen(L, k.shape[-1]) if k.dim() == 2 else conv.seqlen
+    if n != conv.seqlen:
+        conv = conv._fitted_module(n)
     # (the strided launchers address one tensor with 31-bit element offsets: (B-1) * 3*D*L + D*L has to stay below 2^31,
     # where the composition on contiguous copies only needs B*D*L < 2^31)
     too_wide = (uc.shape[0] - 1) * 3 * D * L + D * L >= 2 ** 31

@@ -140,6 +140,7 @@ def test_fft_131072_route_is_shared_by_the_wrappers():
     assert not m._big and not m._route_big(65536) and m._route_big(65537)
     assert "_route_big" in inspect.getsource(sharding.BatchShardedFFTConv.forward)
     assert "_route_big" in inspect.getsource(hyena.gated_conv_from_slices)
+    assert "_fit_seqlen" in inspect.getsource(hyena.gated_conv_from_slices)      # and fits the fft size to the rows like the module
 
 
 def test_fft_size_fits_the_rows():

@@ -19,7 +19,10 @@ def rel(a, b):
                                              (2, 128, 8192, 16384, torch.float16), (4, 256, 16384, 32768, torch.bfloat16),
                                              (2, 32, 32768, 65536, torch.bfloat16), (2, 16, 65536, 131072, torch.bfloat16),
                                              (1, 16, 131072, 262144, torch.bfloat16), (2, 40, 512, 1024, torch.bfloat16),
-                                             (2, 24, 1000, 4096, torch.bfloat16)])
+                                             (2, 24, 1000, 4096, torch.bfloat16),
+                                             # an operator built for a longer sequence than it is run on: the fft size fitted to the rows
+                                             # (FlashFFTConv._fit_seqlen: 16384 / 65536 points, the slices still read in place)
+                                             (2, 16, 8192, 131072, torch.bfloat16), (1, 8, 20000, 1048576, torch.bfloat16)])
 def test_hyena_op_matches_reference_composition(B, D, L, fft, dtype):
     from flashfftconv import FlashHyenaOp, FlashFFTConv, FlashDepthWiseConv1d
     torch.manual_seed(11)
