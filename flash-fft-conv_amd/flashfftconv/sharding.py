@@ -525,20 +525,27 @@ class BatchShardedFFTConv(torch.nn.Module):
         if pregate is not None or postgate is not None:
             assert pregate is not None and postgate is not None
         mode = self.mode
+        conv = self.conv
+        if self._ops is None and hasattr(conv, "_fit_seqlen") and u.dim() == 3 and k.dim() == 2:
+            # rows much shorter than the fft size: the smallest size that holds them, as the single-rank module (FlashFFTConv._fit_seqlen;
+            # every rank sees the same row lengths, so every rank picks the same size)
+            n = conv._fit_seqlen(u.shape[-1], k.shape[-1])
+            if n != conv.seqlen:
+                conv = conv._fitted_module(n)
         if self._ops is None and mode == "allgather_kf":
-            if self.conv._folded or self.conv._kf_keep is not None:
+            if conv._folded or conv._kf_keep is not None:
                 mode = "recompute"          # (periodised k / masked k_f: not worth an exchange path of their own)
         if mode == "recompute":
             kk = _AllReduceGrad.apply(k, self.group)
-            return self.conv(u, kk, pregate, postgate) if pregate is not None else self.conv(u, kk)
+            return conv(u, kk, pregate, postgate) if pregate is not None else conv(u, kk)
         if self._ops is not None:
             ops = self._ops
-        elif self.conv._big or self.conv._route_big(max(u.shape[-1], k.shape[-1])):
+        elif conv._big or conv._route_big(max(u.shape[-1], k.shape[-1])):
             # (fft 131072 with rows longer than N/2 takes the HBM-level form in the single-rank module: the same route here)
-            ops = _BigOps(self.conv, u.device, max(u.shape[-1], k.shape[-1]))
+            ops = _BigOps(conv, u.device, max(u.shape[-1], k.shape[-1]))
         else:
-            ops = _HipOps(self.conv, u.device)
-        training = self.conv.training if hasattr(self.conv, "training") else True
+            ops = _HipOps(conv, u.device)
+        training = conv.training if hasattr(conv, "training") else True
         keep = training and torch.is_grad_enabled()      # spectra are only worth storing when a graph is being recorded
         world = dist.get_world_size(self.group)
         ng = self.groups if self.groups is not None else _default_groups(k.shape[0], world, ops)
@@ -546,7 +553,7 @@ class BatchShardedFFTConv(torch.nn.Module):
             ng = 1
         if self._ops is None:
             from .conv import _check_inputs
-            _check_inputs(self.conv, u, k, (pregate, postgate))
+            _check_inputs(conv, u, k, (pregate, postgate))
             with torch.cuda.device(u.device):
                 return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep, ng)
         return _BShardFn.apply(u, k, pregate, postgate, ops, self.group, training, keep, ng)

@@ -37,11 +37,16 @@ def _body(rank, world, port, q):
     rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
     ok = {}
     dev = torch.device("cuda", 0)
-    for (N, B, H, L, gated) in ((4096, 4, 16, 2048, False), (32768, 4, 10, 16384, True), (1024, 8, 7, 1024, False),
-                                (65536, 4, 6, 32768, False), (262144, 4, 6, 131072, False), (524288, 4, 4, 262144, True),
-                                (2097152, 4, 2, 524288, False)):      # one level of 64 x 32768 (L <= N/2), also in the B-shard (round 4); B = 4 so that
-                                # a rank's rows are whole pairs of the full batch (a row packed with a zero partner differs from the same row packed with
-                                # its neighbour by the bf16 rounding of the shared spectrum, ~3e-3)
+    cases = ((4096, 4, 16, 2048, False, True), (32768, 4, 10, 16384, True, True), (1024, 8, 7, 1024, False, True),
+             (65536, 4, 6, 32768, False, True), (262144, 4, 6, 131072, False, True), (524288, 4, 4, 262144, True, True),
+             # one level of 64 x 32768 (L <= N/2), also in the B-shard (round 4); B = 4 so that a rank's rows are whole pairs of the full
+             # batch (a row packed with a zero partner differs from the same row packed with its neighbour by the bf16 rounding of the
+             # shared spectrum, ~3e-3).  Round 5: these rows fit 1048576 points (FlashFFTConv._fit_seqlen); fit_fft off keeps the
+             # 2097152-point form under test ...
+             (2097152, 4, 2, 524288, False, False),
+             # ... and this one runs fitted: 65536 points hold the rows of a 262144-point module, in the module, the H-shard and the B-shard alike
+             (262144, 4, 4, 32768, False, True))
+    for (N, B, H, L, gated, fit) in cases[-int(os.environ.get("FFC_SHARD_TEST_LAST", len(cases))):]:
         torch.manual_seed(7)                      # same inputs on both ranks
         dt = torch.bfloat16
         mk = lambda: torch.randn(B, H, L, device=dev).to(dt)
@@ -49,6 +54,7 @@ def _body(rank, world, port, q):
         k = torch.randn(H, L, device=dev) * 0.1
         gates = [mk(), mk()] if gated else []
         mod = FlashFFTConv(N, dtype=dt).to(dev)
+        mod.fit_fft = fit
         # single-rank HIP result + oracle
         lv = [t.clone().requires_grad_(True) for t in [u, k] + gates]
         full = mod(*lv)
@@ -56,7 +62,9 @@ def _body(rank, world, port, q):
         lo = [t.clone().requires_grad_(True) for t in [u, k] + gates]
         oref = ref_fft_conv(lo[0] * lo[2], lo[1], N) * lo[3] if gated else ref_fft_conv(lo[0], lo[1], N)
         goref = torch.autograd.grad(oref, lo, dout)
-        tag = f"N{N}"
+        tag = f"N{N}_L{L}"
+        if fit and N > 32768 and 2 * L - 1 <= N // 2:
+            ok[tag + "_runs_fitted"] = set(mod._fitted) == {mod._fit_seqlen(L, L)} and mod._fit_seqlen(L, L) < N
         # ---- H-shard with the differentiable gather
         hv = [t.clone().requires_grad_(True) for t in [u, k] + gates]
         y = HeadShardedFFTConv(mod, gather=True)(*hv)
