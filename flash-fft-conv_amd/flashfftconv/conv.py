@@ -711,7 +711,9 @@ class FlashFFTConv(torch.nn.Module):
         accepted and discarded on load, so `load_state_dict(strict=True)` of a reference checkpoint works.
       * one tensor must stay below 2^31 elements (B*H*L, and for fft sizes >= 262144 also 2*ceil(B/2)*H*fft_size, the
         complex intermediate): larger calls raise RuntimeError; split the batch.
-      * H % 16 == 0 is NOT required for fft sizes > 32768 (reference README.md:269), L may be any length <= fft size."""
+      * H % 16 == 0 is NOT required for fft sizes > 32768 (reference README.md:269), L may be any length <= fft size.
+      * seqlen > 32768 and rows whose linear convolution fits a smaller fft size (Lu + Lk - 1 <= seqlen / 2): that size runs
+        (_fit_seqlen) -- the same outputs and gradients, nothing wraps at either size; `fit_fft = False` runs seqlen points."""
 
     def __init__(self, seqlen, dtype=torch.float16, use_32_butterfly=True):
         super().__init__()
