@@ -105,6 +105,9 @@ def compact(out):
         fr = {r["row"].split(" ")[0]: r["fft_run"] for r in out["configs"] if r.get("fft_run") not in (None, r.get("fft"))}
         if fr:
             c["configs_fft_run"] = fr
+            # ... and the same module forced to its full size (fit_fft = False), for comparison
+            c["configs_seqlen_points_fwd_bwd_ms"] = {r["row"].split(" ")[0]: [r.get("fwd_ms_seqlen_points"), r.get("bwd_ms_seqlen_points")]
+                                                     for r in out["configs"] if r["row"].split(" ")[0] in fr}
     if out.get("readme_table"):
         c["readme_x_h100"] = {str(r["fft"]): r["speedup_vs_h100_published"] for r in out["readme_table"]}
         if all("bwd_ms_scaled" in r for r in out["readme_table"]):
@@ -485,7 +488,7 @@ def main():
         torch.cuda.empty_cache()
         from benchmarks import sweep as SW
         keep = ("row", "fft", "L", "H_run", "rescaled", "fwd_ms", "bwd_ms", "fwd_ms_min", "bwd_ms_min", "fwd_infer_ms", "timing", "seq_per_s", "tflops_fft_equiv", "fwd_alg_GBs",
-                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes", "graph_step_ms", "fft_run")
+                "bwd_alg_GBs", "fwd_GBs", "bwd_GBs", "fwd_hbm_frac", "bwd_hbm_frac", "peak_mem_bytes", "graph_step_ms", "fft_run", "fwd_ms_seqlen_points", "bwd_ms_seqlen_points")
         out["configs"] = [{kk: r[kk] for kk in keep if kk in r} for r in SW.config_rows()]
         # peak memory of the headline config (module level: save_spectrum on / off, inference forward, torch.fft form)
         out["peak_mem_bytes"] = out["configs"][0].get("peak_mem_bytes")

@@ -121,6 +121,16 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
         step = mod.graphed_step(u, k, dout, *g)
         (t_g, _) = ev_time(step.replay, iters)
         del step
+    # a module that ran a smaller fft size than it was built for (FlashFFTConv._fit_seqlen, config 4): the seqlen-point run next to it
+    unfit = None
+    if mod._fit_seqlen(L, L) != N:
+        mod.fit_fft = False
+        (tu_f, _) = ev_time(lambda: mod(u, k, *g), iters)
+        y = mod(u, k, *g)
+        (tu_b, _) = ev_time(bwd, iters)
+        del y
+        mod.fit_fft = True
+        unfit = (tu_f, tu_b)
     pm = peak_mem_row(mod, u, k, g, dout, N)
     scale = H / Hrun
     t_f, t_b, t_fi, t_f_min, t_b_min = t_f * scale, t_b * scale, t_fi * scale, t_f_min * scale, t_b_min * scale
@@ -140,6 +150,7 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
                       "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4),
                       # fft size the module ran: the smallest one that holds the rows' linear convolution (FlashFFTConv._fit_seqlen)
                       "fft_run": mod._fit_seqlen(L, L),
+                      **({"fwd_ms_seqlen_points": round(unfit[0] * scale, 4), "bwd_ms_seqlen_points": round(unfit[1] * scale, 4)} if unfit else {}),
                       "peak_mem_bytes": pm, **({"graph_step_ms": round(t_g * scale, 4)} if t_g is not None else {})})
 
 

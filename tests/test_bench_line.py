@@ -51,3 +51,18 @@ def test_multi_gpu_line_carries_strong_and_weak():
     d = json.loads(bench.emit(out, None, stream=buf))
     assert buf.getvalue().count("\n") == 1 and d["strong"]["heads_per_rank"] == 96 and d["weak"]["value"] == 8e7
     assert "workload" not in d["strong"]
+
+
+def test_rows_that_ran_a_fitted_fft_size_are_flagged_on_the_line(tmp_path):
+    """round 5 (FlashFFTConv._fit_seqlen): a config row whose module ran a smaller fft size than it was built for says so on the contract
+    line, with the seqlen-point timing of the same module next to it; the final round-5 object stays under the limit with them"""
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")))
+    for r in out["configs"]:
+        if r["row"].startswith("cfg4"):
+            r.update(fft_run=2097152, fwd_ms_seqlen_points=0.6864, bwd_ms_seqlen_points=0.7577)
+    buf = io.StringIO()
+    last = bench.emit(out, str(tmp_path / "bench_full.json"), stream=buf)
+    d = json.loads(last)
+    assert len(last) < bench.LINE_LIMIT
+    assert d["configs_fft_run"] == {"cfg4": 2097152} and d["configs_seqlen_points_fwd_bwd_ms"] == {"cfg4": [0.6864, 0.7577]}
+    assert d["configs_fwd_bwd_ms"]["cfg4"][0] < 0.6
