@@ -39,6 +39,9 @@ def main():
         (32768, 32768, 1, 2, torch.float16, True),
         # fft sizes >= 65536 (outer levels through HBM), gated, unit-scale gates: L = N/2 and L = N/4
         (65536, 32768, 2, 2, torch.bfloat16, True), (262144, 65536, 1, 1, torch.float16, True),
+        # rows much shorter than the fft size: the reference transforms N points, this package the smallest size that holds the rows
+        # (FlashFFTConv._fit_seqlen: 32768 resp. 65536 points here; 262144 / 65536 above runs 131072) -- the same numbers
+        (131072, 16384, 2, 2, torch.bfloat16, False), (1048576, 20000, 1, 2, torch.bfloat16, True),
     ]
     only_new = "--only-new" in sys.argv
     for (N, L, B, H, dtype, gated) in cases:

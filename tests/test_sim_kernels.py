@@ -128,7 +128,7 @@ def test_dk_path(N, L, B, H, nch, gated, dt):
 def test_golden_forward_through_simulator():
     """Committed golden vectors (reference oracle outputs) vs the simulated kernels."""
     import glob, os
-    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_N*_plain.npz")))[:5]:
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_N*_plain.npz")))[:6]:
         g = np.load(path)
         N = int(g["N"]); dt = 0 if str(g["dtype"]) == "bfloat16" else 1
         k = g["k"]
