@@ -45,7 +45,10 @@ def _body(rank, world, port, q):
              # 2097152-point form under test ...
              (2097152, 4, 2, 524288, False, False),
              # ... and this one runs fitted: 65536 points hold the rows of a 262144-point module, in the module, the H-shard and the B-shard alike
-             (262144, 4, 4, 32768, False, True))
+             (262144, 4, 4, 32768, False, True),
+             # fft 131072 with rows longer than N/2: the single-rank module routes them to the HBM-level form (FlashFFTConv._route_big), and so
+             # must the B-shard
+             (131072, 4, 4, 131072, False, True))
     for (N, B, H, L, gated, fit) in cases[-int(os.environ.get("FFC_SHARD_TEST_LAST", len(cases))):]:
         torch.manual_seed(7)                      # same inputs on both ranks
         dt = torch.bfloat16
