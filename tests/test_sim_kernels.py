@@ -70,7 +70,8 @@ def test_conv_gated_and_conj(N, dt):
     assert rel(du, dref) < TOL[dt]
 
 
-@pytest.mark.parametrize("N,L", [(256, 2), (256, 250), (1024, 1002), (4096, 2050), (8192, 36), (32768, 16390)])
+@pytest.mark.parametrize("N,L", [(256, 2), (256, 250), (1024, 1002), (4096, 2050), (8192, 36), (32768, 16390),
+                                 (16384, 5001), (16384, 8200), (16384, 16383)])      # fft 16384: the forward with the folded outer twiddle
 def test_conv_ragged_lengths(N, L):
     """L not a multiple of 8 takes the element-wise I/O path; tiny and odd-ish lengths included."""
     rng = np.random.default_rng(L)
