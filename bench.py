@@ -78,6 +78,9 @@ def compact(out):
         if out.get(k):
             r = {kk: out[k][kk] for kk in ROOF_KEYS if kk in out[k]}
             r["kernel"] = r["kernel"].split(":")[0].split(" (")[0][:80]
+            tp = out[k].get("traffic_profiled")
+            if tp:      # `traffic` is read from a committed rocprofv3 --pmc summary, not measured in this run: say which one
+                r["traffic_source"] = f"{tp['file']}#{tp['sha256_16']}"
             c[k] = r
     if out.get("cpu_baseline"):
         c["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in CPU_KEYS if k in out["cpu_baseline"]}
@@ -87,6 +90,10 @@ def compact(out):
             for drop in ("how", "guide_figures", "what", "workload"):
                 v.pop(drop, None)
             c[k] = v
+    # BASELINE's metric is "TFLOP/s & seq/s": both TFLOP/s figures of the headline step ride on the line (VERDICT r05 missing #5)
+    for k in ("tflops_fft_equiv", "tflops_dense_monarch"):
+        if out.get(k) is not None:
+            c[k] = out[k]
     if out.get("ms_per_step_torch_benchmark_timer") is not None:
         c["ms_per_step_timer"] = out["ms_per_step_torch_benchmark_timer"]
     if out.get("preheat_steps") is not None:
@@ -112,6 +119,10 @@ def compact(out):
         c["readme_x_h100"] = {str(r["fft"]): r["speedup_vs_h100_published"] for r in out["readme_table"]}
         if all("bwd_ms_scaled" in r for r in out["readme_table"]):
             c["readme_gated_fwd_bwd_ms"] = {str(r["fft"]): [r["fwd_ms_scaled_to_B64_H768"], r["bwd_ms_scaled"]] for r in out["readme_table"]}
+    if out.get("strong_rows"):      # N > 1: the fixed-problem rows of the metric's grid, [fwd+bwd ms, heads per rank] (max over ranks)
+        c["strong_rows_step_ms"] = {r["row"]: [r["step_ms"], r["heads_per_rank"]] for r in out["strong_rows"]}
+    if out.get("scaling_note"):
+        c["scaling_note"] = out["scaling_note"]
     if out.get("full"):
         c["full"] = out["full"]
     return _r(c)
@@ -120,7 +131,7 @@ def compact(out):
 def emit(out, full_path=None, stream=None):
     """table rows (one JSON line each), the full object to `full_path`, then the contract line -- LAST, < LINE_LIMIT bytes"""
     stream = stream or sys.stdout
-    for table in ("configs", "sweep", "sweep_gated", "readme_table"):
+    for table in ("configs", "sweep", "sweep_gated", "readme_table", "strong_rows"):
         for r in out.get(table) or ():
             print(json.dumps(_row_line(table, r)), file=stream, flush=True)
     if full_path:
@@ -233,6 +244,42 @@ def timed_steps(step, steps, warmup, dist, dev):
     return el
 
 
+# N > 1: the rest of BASELINE's metric ("B=16 H=768 L in 1K .. 1M, 1/2/4/8 GPU" and configs[3] "1 vs 8 GPU H-sharded") as STRONG-scaled rows:
+# the fixed problem, this rank's share of the heads, no data-path collective; fwd+bwd per step, barrier-bracketed, max over ranks
+# (reference harness for the grid: benchmarks/benchmark_flashfftconv.py:94-212).  Heads above the single-GPU sweep's memory cap are
+# rescaled linearly, as that sweep (and the reference's own benchmark) does; the row says so.
+STRONG_ROWS = [("sweep L=1024", 2048, 16, 768, 1024), ("sweep L=16384", 32768, 16, 768, 16384), ("sweep L=131072", 262144, 16, 768, 131072),
+               ("sweep L=1048576", 2097152, 16, 768, 1048576), ("cfg4 H-sharded", 4194304, 1, 16, 1048576)]
+
+
+def strong_scaled_rows(world, rank, dist, dev, rows=None, steps=None):
+    from flashfftconv import FlashFFTConv
+    from flashfftconv.sharding import head_range
+    out = []
+    for (name, N, B, H, L) in (rows or STRONG_ROWS):
+        s0, s1 = head_range(H, rank, world)
+        hr = s1 - s0
+        cap = H if N <= 131072 else max(1, (768 * 131072 // N) * 16 // B)      # heads one GPU holds at this size (benchmarks/sweep.py sweep_rows)
+        hrun = max(1, min(hr, cap))
+        u = torch.randn(B, hrun, L, device=dev).to(CFG["dtype"]).requires_grad_(True)
+        k = torch.randn(hrun, L, device=dev).requires_grad_(True)
+        dout = torch.randn(B, hrun, L, device=dev).to(CFG["dtype"])
+        mod = FlashFFTConv(N, dtype=CFG["dtype"]).to(dev)
+
+        def step():
+            u.grad = None; k.grad = None
+            mod(u, k).backward(dout)
+        n = steps or (10 if N <= 262144 else 3)
+        el = timed_steps(step, n, 2, dist, dev)
+        ms = el / n * 1e3 * (hr / hrun)
+        out.append({"row": name, "fft": N, "fft_run": mod._fit_seqlen(L, L), "B": B, "H": H, "L": L, "n_gpus": world, "heads_per_rank": hr, "H_run": hrun,
+                    "rescaled": hrun != hr, "step_ms": ms, "seq_per_s": B * H / (ms * 1e-3), "scaling": "strong",
+                    "timing": f"fwd+bwd, {n} steps between barriers, max over {world} ranks"})
+        del u, k, dout, mod
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +354,11 @@ def main():
         strong = {"value": B * H / (el_s / args.steps), "unit": "seq/s", "ms_per_step": el_s / args.steps * 1e3,
                   "scaling": "strong", "heads_per_rank": s1 - s0,
                   "workload": f"the fixed B={B} H={H} L={L} problem, {H}//{world} heads per rank"}
+
+    strong_rows = None
+    if world > 1 and not args.no_sweep:
+        sel = os.environ.get("FFC_BENCH_STRONG_ROWS")      # test hook: a comma-separated subset of the row names
+        strong_rows = strong_scaled_rows(world, rank, dist, dev, [r for r in STRONG_ROWS if not sel or r[0] in sel.split(",")])
 
     # ---- per-kernel timing (rank 0 reports): the launches of one step
     plan = mod._get_plan(dev)
@@ -461,8 +513,9 @@ def main():
         "config": {"workload": "FlashFFTConv(32768) B=16 H=768 L=16384 bf16, fwd+bwd incl. k->k_f and dk (BASELINE configs[1])",
                    "rows_per_step": rows, "heads_per_rank": (strong or {}).get("heads_per_rank", H),
                    "parallelism": f"head-shard x{world} (no collective)"},
-        "tflops_dense_monarch": world * rows * dense_fwd * 2.5 / sec_per_step / 1e12,
-        "tflops_fft_equiv": world * rows * (fft_fwd + fft_bwd) / sec_per_step / 1e12,
+        # TFLOP/s of the SAME step as `value` (N > 1: the fixed problem's rows over the strong-scaled step)
+        "tflops_dense_monarch": rows * dense_fwd * 2.5 / (head_ms * 1e-3) / 1e12,
+        "tflops_fft_equiv": rows * (fft_fwd + fft_bwd) / (head_ms * 1e-3) / 1e12,
         "kernel_ms": {n: v * 1e3 for n, v in kt_step.items()},
         "kernel_ms_how": "HIP events between the launches of 20 back-to-back steps: conv_fwd_k + conv_bwd_k = the module's two launches "
                          "(round 4); kfft / conv_fwd_save / bwd_fused_saved / dk_ifft = the same work as round 3's four launches",
@@ -481,6 +534,11 @@ def main():
     }
     if strong is not None:
         out["strong"], out["weak"] = strong, weak
+        out["kernel_ms_scaling"] = "weak"      # kernel_ms / roofline objects below time the full per-GPU shape (768 heads on this rank)
+    if strong_rows:
+        out["strong_rows"] = strong_rows
+    # one place that says it: no multi-GPU run has ever been measured by the builder (every box has ONE GPU; RCCL has only run world-size-1)
+    out["scaling_note"] = "N>1 never measured by the builder: 1-GPU boxes only" if world == 1 else None
     if world == 1 and not args.no_sweep:
         # the rest of the BASELINE metric, timed in this same process with HIP events (benchmarks/sweep.py): the other
         # configs and the L = 1K .. 1M sweep at B=16 H=768 (fwd / bwd ms at module level, incl. k -> k_f and dk)

@@ -30,8 +30,11 @@ def check_agpr(asm_path):
     import re
     from collections import Counter
     mine = re.compile(r"^\s*v_accvgpr_(read_b32 v\d+, a(\d+)|write_b32 a(\d+), (?:v\d+|0))\s*$")
+    # round 6: the sums are accumulated by MFMAs written in inline asm (DevB::mfma_acc_bf16): destination = C = one aligned 16-register tuple
+    # of a0..a127, operands in architectural VGPRs
+    mine_mfma = re.compile(r"^\s*v_mfma_f32_32x32x16_bf16 a\[(\d+):(\d+)\], v\[\d+:\d+\], v\[\d+:\d+\], a\[(\d+):(\d+)\]\s*$")
     areg = re.compile(r"\ba\[\d+:\d+\]|\ba\d+\b")
-    kernel, reads, writes, bad = None, Counter(), Counter(), []
+    kernel, reads, writes, mfmas, bad = None, Counter(), Counter(), Counter(), []
 
     def close():
         # every accumulator is zeroed + updated (2 writes) and read for the update + the final store (2 reads), in the kernels
@@ -43,13 +46,18 @@ def check_agpr(asm_path):
                                            and not kernel.startswith("_Z10bwd_kernelIN3ffc3GeoILi16ELi16ELi16EEE"))
                                           or kernel.startswith("_Z13bwd_rp_kernelIN3ffc3GeoILi32ELi32ELi32EEELi0E"))   # bf16 multi-pass: dk_tail_rp
         counts = set()
-        for idx in set(reads) | set(writes):
+        # MFMA-accumulated sums (round 6): zeroed (1 write), accumulated by the matrix pipe, read for the final store (1 read) and, in the
+        # kernels with the tail, once more; VALU-accumulated sums (FFC_WACC_MFMA=0 builds): one more read and write per register for the update
+        upd = 0 if mfmas else 1
+        for idx in set(reads) | set(writes) | set(mfmas):
             counts.add(reads[idx])
-            if reads[idx] not in ((2, 3) if tail_ok else (2,)) or writes[idx] != 2:
+            if reads[idx] not in ((1 + upd, 2 + upd) if tail_ok else (1 + upd,)) or writes[idx] != 1 + upd:
                 bad.append(f"{kernel}: a{idx} read {reads[idx]}x written {writes[idx]}x")
+            if mfmas and mfmas[idx] != max(mfmas.values()):
+                bad.append(f"{kernel}: a{idx} accumulated by {mfmas[idx]} MFMAs, others by {max(mfmas.values())}")
         if len(counts) > 1:
             bad.append(f"{kernel}: accumulation registers read unevenly ({sorted(counts)} reads)")
-        reads.clear(); writes.clear()
+        reads.clear(); writes.clear(); mfmas.clear()
 
     with open(asm_path) as fh:
         for line in fh:
@@ -62,6 +70,14 @@ def check_agpr(asm_path):
                 continue
             if areg.search(t):
                 mm = mine.match(t)
+                mf = mine_mfma.match(t)
+                if mf:
+                    lo, hi = int(mf.group(1)), int(mf.group(2))
+                    if (lo, hi) != (int(mf.group(3)), int(mf.group(4))) or hi - lo != 15 or lo % 16 or hi > 127:
+                        bad.append(f"{kernel}: {t.strip()}")
+                    for i in range(lo, hi + 1):
+                        mfmas[str(i)] += 1
+                    continue
                 if not mm:
                     bad.append(f"{kernel}: {t.strip()}")
                 elif mm.group(2) is not None:

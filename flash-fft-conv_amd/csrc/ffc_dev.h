@@ -126,6 +126,16 @@ struct DevB {
     return x;
   }
   template <int I> static FFC_FN void agpr_set(f32 x) { asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"n"(I), "v"(x)); }
+  // Round 6: acc[I0 .. I0+15] (accumulation registers) += A x B, bf16 operands.  The dk_f sums are accumulated by the matrix pipe (Modes::
+  // w_acc_tile: B = the products D (x) conj Z rounded to bf16, A = a permuted identity), so the VALU never shuttles them through
+  // v_accvgpr_read / v_accvgpr_write.  Inline asm (the compiler keeps its own MFMAs in VGPR form and must not see a0..a127): the wait states
+  // are ours (cdna_hip_programming.md 5.7 item 2) -- `s_nop 1` covers the VALU-written A / B operands; an MFMA that takes the previous
+  // one's destination whole as C needs none; readers of the sums call mfma_settle() first.
+  template <int I0> static FFC_FN void mfma_acc_bf16(const W4& a, const W4& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(I0), "n"(I0 + 15));
+  }
+  // an MFMA's destination -> any reader other than the next accumulating MFMA: 12 wait states for the 8-pass 32x32x16 (ibid.)
+  static FFC_FN void mfma_settle() { asm volatile("s_nop 15"); }
   // keep a load-defined MFMA operand in architectural VGPRs (the allocator may otherwise place it in the
   // accumulation registers, which hold the dk_f partial sums in the backward kernels)
   static FFC_FN void pin(W4& x) { asm("" : "+v"(x)); }

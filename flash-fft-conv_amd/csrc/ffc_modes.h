@@ -580,11 +580,60 @@ struct Modes : Body<B, GEO, DT> {
       }
     }
   }
+  // Round 6 experiment (FFC_WACC_MFMA = 1; measured, NOT adopted: profiles/r06_ab_wacc_mfma.txt): the sums accumulated by the MATRIX pipe.
+  // The fp32 products P = D (x) conj Z of a tile are rounded to bf16 MFMA operands (to_op form: operand dword d of K-step ms =
+  // pack(P[8 ms + 2 d], P[8 ms + 2 d + 1]), whose contraction slot (ms, lane half, e) carries accumulator row kslot_row(ms, hi, e),
+  // ffc_layout.h) and multiplied by a permuted identity straight into a[32 T ..]: W += I x P, exact fp32 accumulation of bf16-rounded
+  // products.  It removes the 128 v_accvgpr_read / _write + 16 packed adds per tile and pair of the VALU form for 16 v_cvt_pk + ~25 VALU
+  // (identity operands) + 4 MFMAs -- about 350 issue cycles per tile on the r03 cost table -- and the backward kernels run EXACTLY as
+  // fast as before (config 2: 0.6222 / 0.6236 / 0.6207 against 0.6199 / 0.6081 / 0.6236 ms, same box, interleaved; fft 4096 5 % slower):
+  // the accumulation is not on the critical path of the pair loop.  Parity-green on the simulator (209 cases) and the GPU.  Default 0.
+#ifndef FFC_WACC_MFMA
+#define FFC_WACC_MFMA 0
+#endif
+  // A operand of the identity K-step ms: lane (i = lane & 31, hi' = lane >> 5), slot e: 1.0 iff i == kslot_row(ms, hi', e)
+  static FFC_FN W4 ident_op(int ms) {
+    const i32 lane = B::opaque(B::lane());
+    const i32 t = (lane & 31) - (lane >> 5) * 4 - 16 * ms;      // = 8 (e >> 2) + (e & 3) for the matching slot, if any
+    const pred ok = (t >= 0) && ((t & 4) < 1) && (t < 12);
+    const i32 e = (t & 3) + ((t >> 3) << 2);
+    const u32 one = B::sel((e & 1) >= 1, B::uconst(0x3F800000u), B::uconst(0x00003F80u));
+    W4 w;
+#pragma unroll
+    for (int d = 0; d < 4; d++) w[d] = B::sel(ok && ((e >> 1) < d + 1) && ((e >> 1) >= d), one, B::uconst(0));
+    return w;
+  }
+  // products of accumulator rows 4 RQ .. 4 RQ + 3 with the conjugated spectrum quad z -> two operand dwords per component
+  static FFC_FN void w_prod_quarter(int RQ, const U4& z, const A16& re, const A16& im, u32 (&pr)[2], u32 (&pi)[2]) {
+    u32 wv[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int r0 = 4 * RQ + 2 * j;
+      f32 zr0 = B::template unpack_lo<DT>(wv[2 * j]), zi0 = B::template unpack_hi<DT>(wv[2 * j]);
+      f32 zr1 = B::template unpack_lo<DT>(wv[2 * j + 1]), zi1 = B::template unpack_hi<DT>(wv[2 * j + 1]);
+      f32 p0 = re[r0] * zr0 + im[r0] * zi0, p1 = re[r0 + 1] * zr1 + im[r0 + 1] * zi1;
+      f32 q0 = im[r0] * zr0 - re[r0] * zi0, q1 = im[r0 + 1] * zr1 - re[r0 + 1] * zi1;
+      pr[j] = B::template pack<DT_BF16>(p0, p1);
+      pi[j] = B::template pack<DT_BF16>(q0, q1);
+    }
+  }
   template <int T>
   static FFC_FN void w_acc_tile(const typename BD::KfRegs& zv, const A16& re, const A16& im) {
 #if defined(FFC_KO) && (FFC_KO & 128)
     return;        // knock-out timing experiment: no dk_f accumulation
 #endif
+    if constexpr (FFC_WACC_MFMA != 0) {
+#pragma unroll
+      for (int ms = 0; ms < 2; ms++) {
+        u32 r01[2], i01[2], r23[2], i23[2];
+        w_prod_quarter(2 * ms, zv.v[2 * ms], re, im, r01, i01);
+        w_prod_quarter(2 * ms + 1, zv.v[2 * ms + 1], re, im, r23, i23);
+        const W4 id = ident_op(ms);
+        B::template mfma_acc_bf16<32 * T>(id, B::w4(r01[0], r01[1], r23[0], r23[1]));
+        B::template mfma_acc_bf16<32 * T + 16>(id, B::w4(i01[0], i01[1], i23[0], i23[1]));
+      }
+      return;
+    }
     w_acc_quarter<T, 0>(zv.v[0], re, im);
     w_acc_quarter<T, 1>(zv.v[1], re, im);
     w_acc_quarter<T, 2>(zv.v[2], re, im);

@@ -99,6 +99,9 @@ struct SimB {
   static void agpr_reserve() {}
   template <int I> static f32 agpr_get() { return g_agpr[I]; }
   template <int I> static void agpr_set(const f32& x) { g_agpr[I] = x; }
+  // DevB::mfma_acc_bf16: a[I0 .. I0+15] += A x B (bf16 operands); defined behind mfma<>
+  template <int I0> static void mfma_acc_bf16(const struct W4& a, const struct W4& b);
+  static void mfma_settle() {}
   static void pin(W4&) {}
   static void pin4(U4&) {}
   static void sched_fence() {}
@@ -310,6 +313,12 @@ struct SimB {
   template <int DT> static f32 unpack_lo(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)a.v[i]); return r; }
   template <int DT> static f32 unpack_hi(const u32& a) { f32 r; for (int i = 0; i < 64; i++) r.v[i] = dt_to_f32(DT, (uint16_t)(a.v[i] >> 16)); return r; }
 };
+template <int I0> void SimB::mfma_acc_bf16(const SimB::W4& a, const SimB::W4& b) {
+  A16 acc;
+  for (int r = 0; r < 16; r++) acc[r] = g_agpr[I0 + r];
+  mfma<DT_BF16>(acc, a, b);
+  for (int r = 0; r < 16; r++) g_agpr[I0 + r] = acc[r];
+}
 bool SimB::HAS_TR = true;
 // mirrors DevBO: the backward kernels use the per-tile outer stages
 struct SimBO : SimB { static constexpr bool LEAN_OUTER = true; };

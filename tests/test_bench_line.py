@@ -53,6 +53,29 @@ def test_multi_gpu_line_carries_strong_and_weak():
     assert "workload" not in d["strong"]
 
 
+def test_line_carries_tflops_traffic_source_and_the_strong_rows(tmp_path):
+    """round 6 (VERDICT r05 missing #4 / #5, weak #11): BASELINE's metric is "TFLOP/s & seq/s" -- both TFLOP/s figures ride on the contract
+    line; `roofline.traffic` comes out of a committed rocprofv3 summary and the line names it (file # sha16); an N > 1 run carries the
+    strong-scaled rows of the metric's grid as [fwd+bwd ms, heads per rank]"""
+    out = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")))
+    out.update(n_gpus=8, scaling="strong", strong_rows=[
+        {"row": n, "fft": 2 * L, "fft_run": 2 * L, "B": 16, "H": 768, "L": L, "n_gpus": 8, "heads_per_rank": 96, "H_run": 96, "rescaled": False,
+         "step_ms": 0.1234567 * (i + 1), "seq_per_s": 1e6, "scaling": "strong", "timing": "fwd+bwd, 10 steps between barriers, max over 8 ranks"}
+        for i, (n, L) in enumerate((("sweep L=1024", 1024), ("sweep L=16384", 16384), ("sweep L=131072", 131072), ("sweep L=1048576", 1048576)))] +
+        [{"row": "cfg4 H-sharded", "fft": 4194304, "fft_run": 2097152, "B": 1, "H": 16, "L": 1048576, "n_gpus": 8, "heads_per_rank": 2, "H_run": 2,
+          "rescaled": False, "step_ms": 0.2, "seq_per_s": 8e4, "scaling": "strong", "timing": "x"}])
+    buf = io.StringIO()
+    last = bench.emit(out, str(tmp_path / "bench_full.json"), stream=buf)
+    d = json.loads(last)
+    assert len(last) < bench.LINE_LIMIT
+    assert d["tflops_fft_equiv"] == round(out["tflops_fft_equiv"], 3) and d["tflops_dense_monarch"] > d["tflops_fft_equiv"]
+    src = d["roofline"]["traffic_source"]
+    assert src.startswith("profiles/r0") and "#" in src and len(src.split("#")[1]) == 16
+    assert d["strong_rows_step_ms"]["cfg4 H-sharded"] == [0.2, 2] and len(d["strong_rows_step_ms"]) == 5
+    rows = [json.loads(l) for l in buf.getvalue().splitlines()[:-1]]
+    assert sum(r["table"] == "strong_rows" for r in rows) == 5
+
+
 def test_rows_that_ran_a_fitted_fft_size_are_flagged_on_the_line(tmp_path):
     """round 5 (FlashFFTConv._fit_seqlen): a config row whose module ran a smaller fft size than it was built for says so on the contract
     line, with the seqlen-point timing of the same module next to it; the final round-5 object stays under the limit with them"""
