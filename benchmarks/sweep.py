@@ -98,6 +98,8 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
     dout = torch.randn(B, Hrun, L, device=dev).to(dtype)
     mod = FlashFFTConv(N, dtype=dtype).to(dev)
     iters = set_iters(N)
+    from flashfftconv import conv as _C
+    fb0 = dict(_C.SPECTRUM_FALLBACKS)      # a timed row that silently fell back to the recomputing backward says so
     # forward = the TRAINING forward (grad enabled: it also stores what the backward pass reads, e.g. the spectra of
     # module.save_spectrum); the inference forward (no_grad, eval) is reported next to it
     (t_f, t_f_min) = ev_time(lambda: mod(u, k, *g), iters)
@@ -131,6 +133,7 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
         del y
         mod.fit_fft = True
         unfit = (tu_f, tu_b)
+    fb = {k_: _C.SPECTRUM_FALLBACKS[k_] - fb0[k_] for k_ in fb0 if _C.SPECTRUM_FALLBACKS[k_] != fb0[k_]}
     pm = peak_mem_row(mod, u, k, g, dout, N)
     scale = H / Hrun
     t_f, t_b, t_fi, t_f_min, t_b_min = t_f * scale, t_b * scale, t_fi * scale, t_f_min * scale, t_b_min * scale
@@ -150,6 +153,7 @@ def conv_row(name, N, B, H, L, dtype=torch.bfloat16, gated=False, Hrun=None):
                       "fwd_hbm_frac": round(alg_f / (t_f * 1e-3) / 8e12, 4), "bwd_hbm_frac": round(alg_b / (t_b * 1e-3) / 8e12, 4),
                       # fft size the module ran: the smallest one that holds the rows' linear convolution (FlashFFTConv._fit_seqlen)
                       "fft_run": mod._fit_seqlen(L, L),
+                      **({"spectrum_fallbacks": fb} if fb else {}),
                       **({"fwd_ms_seqlen_points": round(unfit[0] * scale, 4), "bwd_ms_seqlen_points": round(unfit[1] * scale, 4)} if unfit else {}),
                       "peak_mem_bytes": pm, **({"graph_step_ms": round(t_g * scale, 4)} if t_g is not None else {})})
 

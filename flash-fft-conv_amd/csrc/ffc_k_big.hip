@@ -43,14 +43,16 @@ static int launch_big_pipe(const BigArgs& a, int num_cu, hipStream_t st) {
 // GPU parity suite ran green on it and the next attempt (two pipelined workgroups of 32 KB blocks) starts from here.
 template <int N0, int DT, bool FWD>
 static int launch_level(const BigArgs& a, const ffc_plan* p, hipStream_t st) {
-  const bool pipe = a.R == 1 && a.fast && !a.lf32 && !(FWD && a.gate) && (p->env_flags & 16);
+  const bool pipe = a.R == 1 && a.fast && !a.lf32 && !a.half && !(FWD && a.gate) && (p->env_flags & 16);
   return pipe ? launch_big_pipe<N0, DT, FWD>(a, p->num_cu, st) : launch_big<N0, DT, FWD>(a, st);
 }
 
 // `dtype` of the level entry points: bits 0..3 the 16-bit type; | FFC_LONG_F32 (16): the long side is fp32 (dir = 1: `in` is read as
 // float, multiplied by 2^e, e = bits 8..15, and rounded to the 16-bit type; dir = 0: `out` is written as float).  Gates stay 16-bit.
+// | FFC_HALF_ROWS (32): the long side is one REAL row per head (Bv == 1) and the short side holds the rows k0 <= K / 2 only (BigArgs::half).
 static int decode_dtype(int dtype, int dir, BigArgs* a) {
   a->lf32 = (dtype & 16) ? 1 : 0;
+  a->half = (dtype & 32) ? 1 : 0;
   const int e = (dtype >> 8) & 0xff;
   if (e > 30 || (e && !(a->lf32 && dir))) return -1;
   a->lpre = (float)(1u << e);
@@ -72,6 +74,7 @@ extern "C" int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, in
   a.in = in; a.out = out; a.gate = gate;
   dtype = decode_dtype(dtype, dir, &a);
   if (dtype != DT_BF16 && dtype != DT_F16) return ffc_fail("outer pass: bad dtype");
+  if (a.half && (Bv != 1 || npair != 1)) return ffc_fail("outer pass (half rows): one real row per head only (Bv == 1)");
   const bool bf = dtype == DT_BF16;
   a.fmat = (bf ? p->d_blob_bf : p->d_blob) + (bf ? p->hp_bf.tabs.mat[0] : p->hp.tabs.mat[0]);
   if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
@@ -107,6 +110,7 @@ extern "C" int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int di
   a.in = in; a.out = out; a.gate = gate;
   dtype = decode_dtype(dtype, dir, &a);
   if (dtype != DT_BF16 && dtype != DT_F16) return ffc_fail("outer pass: bad dtype");
+  if (a.half && (Bv != 1 || npair != 1)) return ffc_fail("outer pass (half rows): one real row per head only (Bv == 1)");
   const bool bf = dtype == DT_BF16;
   if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
   a.fmat = (bf ? p->d_blob_bf : p->d_blob) + (bf ? p->hp_bf.tabs.matk[c][dir ? 0 : 1] : p->hp.tabs.matk[c][dir ? 0 : 1]);
@@ -146,6 +150,7 @@ extern "C" int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, co
   a.in = in; a.out = out; a.gate = gate;
   dtype = decode_dtype(dtype, dir, &a);
   if (dtype != DT_BF16 && dtype != DT_F16) return ffc_fail("outer pass: bad dtype");
+  if (a.half && (Bv != 1 || npair != 1)) return ffc_fail("outer pass (half rows): one real row per head only (Bv == 1)");
   const bool bf = dtype == DT_BF16;
   if (!bf && p->hp.dtype != DT_F16) return ffc_fail("outer pass: fp16 tables need an fp16 plan");
   for (int c = 0; c < p->hp.R; c++)

@@ -62,7 +62,10 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
                          int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                          int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream, const void* yraw = nullptr,
                          float* dk = nullptr, int64_t Lk = 0, bool* dk_done = nullptr, void* dk_pair = nullptr, float dk_pair_scale = 1.0f) {
-  if (!p || !dout || !u || !kf || !du || !ws) return ffc_fail("null arg");
+  if (!p || !dout || !kf || !du || !ws) return ffc_fail("null arg");
+  // `u` is read by the recomputing kernels, as the gate of dpregate and by the forward run that makes dpostgate without y_raw; on saved
+  // spectra without gates nothing reads it and a null pointer says so (the HBM-level sizes' inner call, flashfftconv/conv.py _big_backward)
+  if (!u && (!zin || pregate || postgate || dpre || (dpost && !yraw))) return ffc_fail("null u: only with saved spectra and no gates");
   if (yraw && (!zin || !dpost)) return ffc_fail("y_raw needs the saved spectra and a dpost output");
   if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");

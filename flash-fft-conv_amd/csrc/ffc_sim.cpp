@@ -341,6 +341,18 @@ static void run_wg(int nwaves, int lds_bytes, F fn) {
 
 template <class GEO, int DT>
 static void sim_conv_t(const ConvArgs& a) {
+  if constexpr (!GEO::OUTER) {
+    if (a.R <= 1) {      // single-tile sizes: persistent workgroups, the next tile in flight (conv_kernel -> Body::conv_small); 3 of them here
+      const int nwg = 3;
+      for (int wg = 0; wg < nwg; wg++)
+        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
+          Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
+          if (a.zsave) Body<SimB, GEO, DT>::template conv_small<true>(a, wg, nwg);
+          else Body<SimB, GEO, DT>::template conv_small<false>(a, wg, nwg);
+        });
+      return;
+    }
+  }
   for (int h = 0; h < a.H; h++)
     for (int c = 0; c < a.nchunk; c++) {
       if constexpr (GEO::N == 32768) {
@@ -593,12 +605,14 @@ int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in,
   if (R > 1 && N0 != 32) return -3;
   // the library's dtype flags (ffc_k_big.hip decode_dtype): | 16 = fp32 long side, bits 8..15 = log2 of the forward prescale
   const int lf32 = (dtype & 16) ? 1 : 0;
+  const int half = (dtype & 32) ? 1 : 0;      // FFC_HALF_ROWS (BigArgs::half)
   const float lpre = (float)(1u << ((dtype >> 8) & 0xff));
   dtype &= 15;
   if (!build_plan(R > 1 ? 32768 * R : (N0 == 16 ? 16384 : 32768), dtype, &p)) return -1;   // only for the N0-point operand table
+  if (half && (Bp_valid != 1 || npair != 1)) return -4;
   BigArgs a{};
   a.R = R; a.c = c;
-  a.lf32 = lf32; a.lpre = lpre;
+  a.lf32 = lf32; a.lpre = lpre; a.half = half;
   a.in = in; a.out = out; a.gate = gate; a.fmat = p.blob.data() + (R > 1 ? p.tabs.matk[c][fwd ? 0 : 1] : p.tabs.mat[0]);
   a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
   a.fast = (Llong % 8 == 0) && !g_force_slow;
@@ -607,7 +621,7 @@ int ffcsim_big_outer_r(int N0, int R, int c, int dtype, int fwd, const void* in,
   const int nwg = npair * Hin * (Mi / cols);
   // the launcher's rule (ffc_k_big.hip launch_level): persistent double-buffered form for plain levels with 16-byte accesses and no
   // input gate; here 3 "workgroups" walk the blocks so that every one of them runs several iterations
-  const bool pipe = g_big_pipe && R == 1 && a.fast && !a.lf32 && !(fwd && gate);
+  const bool pipe = g_big_pipe && R == 1 && a.fast && !a.lf32 && !a.half && !(fwd && gate);
   const int npw = pipe ? (nwg < 3 ? nwg : 3) : nwg;
   for (int wg = 0; wg < npw; wg++) {
 #define FFC_BIG(NN, DD, FF) run_wg(GeoBig<NN>::WGW + (pipe ? 1 : 0), pipe ? BigBody<SimB, NN, DD>::PIPE_LDS : GeoBig<NN>::LDS_BYTES, [&]() { \
@@ -626,12 +640,14 @@ int ffcsim_big_outer_all(int R, int dtype, int fwd, const void* in, void* out, c
                          int Hin, int Mi, int Llong, float scale) {
   HostPlan p;
   const int lf32 = (dtype & 16) ? 1 : 0;
+  const int half = (dtype & 32) ? 1 : 0;
   const float lpre = (float)(1u << ((dtype >> 8) & 0xff));
   dtype &= 15;
   if (R < 2 || R > 4 || !build_plan(32768 * R, dtype, &p)) return -1;
+  if (half && (Bp_valid != 1 || npair != 1)) return -4;
   BigArgs a{};
   a.R = R; a.c = 0;
-  a.lf32 = lf32; a.lpre = lpre;
+  a.lf32 = lf32; a.lpre = lpre; a.half = half;
   a.in = in; a.out = out; a.gate = gate;
   for (int c = 0; c < R; c++) a.fmats[c] = p.blob.data() + p.tabs.matk[c][fwd ? 0 : 1];
   a.fmat = a.fmats[0];

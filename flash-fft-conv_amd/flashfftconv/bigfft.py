@@ -63,6 +63,17 @@ def row_freq(N, fac=None):
     return offs, stride
 
 
+def rows_of(ops, n0):
+    """short-side rows per head of a level of factor n0: all n0 of them, or -- ops.half (round 6: ONE REAL row per head on the long side, a
+    batch of one; csrc/ffc_big.h BigArgs::half) -- the n0 / 2 + 1 rows k0 <= n0 / 2, whose conjugate mirrors are never stored or convolved"""
+    return n0 // 2 + 1 if getattr(ops, "half", False) else n0
+
+
+def half_ok(N, B, Lmax, ops=None):
+    """the half-row form applies to a batch of ONE real row per head through a SINGLE level (the mirror relation is per level)"""
+    return B == 1 and len(choose(N, Lmax, ops)[0]) == 1
+
+
 def level_scale(n0):
     """forward scale of one level ~ 1/sqrt(N0) (keeps the spectrum RMS near the input RMS)"""
     return {16: 0.25, 32: 0.125, 64: 0.125, 128: 0.0625}[n0]
@@ -82,12 +93,12 @@ def levels_forward(ops, dt, N, x, B_valid, H, L, gate=None, fac=None, lf32=None)
     Hx, nlev, Llong, bv = H, N, L, B_valid
     for i, n0 in enumerate(factors):
         mi = nlev // n0
-        out = ops.empty_pair(dt, 2 * npair, Hx * n0, mi)
+        out = ops.empty_pair(dt, 2 * npair, Hx * rows_of(ops, n0), mi)
         if i == 0 and lf32 is not None:
             ops.outer(dt, n0, True, x, out, gate, bv, npair, Hx, mi, Llong, level_scale(n0), lf32=lf32)
         else:
             ops.outer(dt, n0, True, x, out, gate if i == 0 else None, bv, npair, Hx, mi, Llong, level_scale(n0))
-        x, Hx, nlev, Llong, bv = out, Hx * n0, mi, mi, 2 * npair
+        x, Hx, nlev, Llong, bv = out, Hx * rows_of(ops, n0), mi, mi, 2 * npair
     return x
 
 
@@ -98,12 +109,12 @@ def levels_inverse(ops, dt, N, y, out, B_valid, H, L, gate=None, shared=None, fa
     npair = y.shape[0] // 2
     Hx = H
     for n0 in factors:
-        Hx *= n0
+        Hx *= rows_of(ops, n0)
     nlev = M
     cur = y
     for i in reversed(range(len(factors))):
         n0 = factors[i]
-        Hx //= n0
+        Hx //= rows_of(ops, n0)
         nlev *= n0
         sc = 1.0 / (n0 * level_scale(n0))
         if i == 0 and lf32:
@@ -184,7 +195,7 @@ def dk_from_slabs(ops, N, ws, Bp, H, Lk, nslab=None, fac=None):
     factors, M = fac or BIG_FACTORS[N]
     hp = H
     for n0 in factors:
-        hp *= n0
+        hp *= rows_of(ops, n0)
     BF = ops.BF16
     sc = 1.0 / (inner_sfwd(M) * prod_scale(N, fac))
     y = ops.dkifft_c(M, ws, Bp, hp, sc) if nslab is None else ops.dkifft_c(M, ws, Bp, hp, sc, nslab)     # (2, hp, M) bf16

@@ -260,8 +260,10 @@ class _TorchOps:
     """GPU backend of flashfftconv.bigfft (FFT sizes >= 65536): thin wrappers over the C-ABI."""
     BF16 = torch.bfloat16
 
-    def __init__(self, mod, device):
-        self.mod, self.device = mod, device
+    def __init__(self, mod, device, half=False):
+        # half (round 6): the long side is ONE REAL row per head (a batch of one) -- the levels keep the rows k0 <= K / 2 only and the inner
+        # kernel convolves half as many (csrc/ffc_big.h BigArgs::half, bigfft.rows_of)
+        self.mod, self.device, self.half = mod, device, half
 
     def _plan(self, N):
         return self.mod._get_plan(self.device, N)
@@ -282,6 +284,9 @@ class _TorchOps:
 
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale, lf32=None):
         dcode = _DT[dt]
+        if self.half:              # | 32: half rows (include/flashfftconv_hip.h, the level entry points' `dtype`)
+            assert bv == 1 and npair == 1
+            dcode |= 32
         if lf32 is not None:       # fp32 long side: | 16, forward prescale 2^e in bits 8..15 (csrc/ffc_k_big.hip decode_dtype)
             e = int(round(math.log2(lf32)))
             assert 2.0 ** e == lf32 and (fwd or e == 0)
@@ -352,7 +357,7 @@ class _TorchOps:
     def bwd_dk(self, dt, M, xd, xu, kf, z, scale):
         """inner backward in ONE call (ffc_conv_bwd_kx): input-gradient rows + the dk rows as a complex pair-plane tensor (bf16)"""
         plan = self._plan(M)
-        Bp, hp, _ = xu.shape
+        Bp, hp, _ = xd.shape
         lib = _lib.lib()
         ws = torch.empty(_ws_bytes(plan, Bp, hp), dtype=torch.uint8, device=self.device)
         yd = torch.empty_like(xd)
@@ -370,7 +375,7 @@ class _TorchOps:
     def bwd(self, dt, M, xd, xu, kf, z=None):
         """fused inner backward on pair-plane rows: (input gradient rows, fp32 dk_f slabs); z = spectra kept by conv_save"""
         plan = self._plan(M)
-        Bp, hp, _ = xu.shape
+        Bp, hp, _ = xd.shape
         lib = _lib.lib()
         ws = torch.empty(lib.ffc_dkf_workspace_bytes(plan.handle, Bp, hp), dtype=torch.uint8, device=self.device)
         yd = torch.empty_like(xd)
@@ -420,13 +425,23 @@ def _big_kf_mask(mod, fac, device, dtype):
     return m
 
 
-def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
+# FFC_BIG_HALF=0: a batch of one runs the pair form with an empty partner row, as every odd last row still does (A/B runs)
+_BIG_HALF = _os.environ.get("FFC_BIG_HALF", "1") != "0"
+
+
+def _big_half(mod, B, Lmax, fac):
+    """a batch of ONE row per head through a single HBM level: the half-row form (bigfft.rows_of) -- not for the frequency-sparse modules,
+    whose masks are laid out over all inner rows"""
+    return _BIG_HALF and B == 1 and mod._kf_keep is None and len((fac or _big.BIG_FACTORS[mod.seqlen])[0]) == 1
+
+
+def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None, half=False):
     """keep (training, module.save_spectrum): also return what the backward pass would otherwise compute again -- the
     transformed input x of the inner size (pair-plane rows), the inner spectra z (inner plans with that path) and, for the
     gated form, the inner output y (dpostgate = its inverse levels * dout).  kf: inner k_f rows computed elsewhere
     (_big_kernel_fft; the B-shard gathers them from the ranks), k is then unused."""
     N, dt = mod.seqlen, mod.dtype
-    ops = _TorchOps(mod, u.device)
+    ops = _TorchOps(mod, u.device, half)
     B, H, L = u.shape
     M = (fac or _big.BIG_FACTORS[N])[1]
     z = None
@@ -438,7 +453,7 @@ def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None):
         y, kf, z = ops.conv_kx(dt, M, x, xk, sc, keep)
     else:
         if kf is None:
-            kf = _big_kernel_fft(mod, k, fac)
+            kf = _big.kernel_fft(ops, mod.dtype, N, k.detach().to(torch.float32).contiguous(), k.shape[0], k.shape[-1], fac)
             if mod._kf_keep is not None:       # frequency-sparse k_f (flashfftconv/sparse_conv.py): zero the inner rows' bins |f| >= keep
                 m = _big_kf_mask(mod, fac, u.device, kf.dtype)
                 kf.view(H, m.shape[0], m.shape[1], 2).mul_(m[None, :, :, None])
@@ -464,11 +479,11 @@ def _big_dk_from_dkf(mod, dkf, k_len, fac=None):
     return _big.dk_from_slabs(ops, mod.seqlen, dkf.contiguous(), 2, h, k_len, nslab=1, fac=fac)
 
 
-def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dkf=False, fac=None):
+def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dkf=False, fac=None, half=False):
     """want_dkf: return the fp32 inner dk_f rows summed over the local batch (hp, kf_elems, 2) instead of dk (B-shard: the
     ranks reduce-scatter them and invert their own heads, _big_dk_from_dkf)"""
     N, dt = mod.seqlen, mod.dtype
-    ops = _TorchOps(mod, u.device)
+    ops = _TorchOps(mod, u.device, half)
     B, H, L = u.shape
     M = (fac or _big.BIG_FACTORS[N])[1]
     xd = _big.levels_forward(ops, dt, N, dout, B, H, L, postgate, fac)
@@ -476,16 +491,18 @@ def _big_backward(mod, dout, u, kf, pregate, postgate, k_len, kept=None, want_dk
     if xu is None:
         if z is None or (pregate is not None and yu is None):      # (cannot happen with what _big_forward keeps)
             xu = _big.levels_forward(ops, dt, N, u, B, H, L, pregate, fac)
-        else:
-            xu = xd       # stand-in of the same shape: with the inner spectra the (ungated) inner kernel does not read its input rows
+        # else: xu stays None -- with the inner spectra the (ungated) inner kernel does not read its input rows, and the C side accepts a
+        # null `u` exactly then (conv_bwd_impl; ADVICE r05: a stand-in pointer would have hidden a kernel that does read it)
     # one fused inner launch (input gradient rows + fp32 dk_f partial sums; two transforms per pair on kept spectra, three
     # otherwise) instead of the dk_f kernel and the conj(k_f) forward kernel side by side (four)
     if not want_dkf and mod._kf_keep is None and _BIG_ONE_CALL:
         # one call: the fused inner backward + the inner dk_f -> complex rows step (out of the same launch where a workgroup owns its row)
-        yd, ypair = ops.bwd_dk(dt, M, xd, xu, kf, z, _big.dk_pair_scale(N, fac))
+        yd, ypair = ops.bwd_dk(dt, M, xd, xu, kf, z, _big.dk_pair_scale(N, fac))      # (xu None: spectra kept)
         dk = _big.dk_from_pair(ops, N, ypair, H, k_len, fac)
         return _big_backward_tail(mod, ops, dt, N, yd, dk, u, dout, xu, yu, kf, pregate, B, H, L, M, fac)
     yd, ws = ops.bwd(dt, M, xd, xu, kf, z)
+    if xu is None:
+        xu = xd          # (shape only, below)
     if mod._kf_keep is not None:
         # d/dk of (mask * FFT(k)): mask the fp32 inner dk_f partial sums (same row / position order as k_f) before the inverse
         plan_m = ops._plan(M)
@@ -567,13 +584,14 @@ class _FlashFFTConvFn(torch.autograd.Function):
                     SPECTRUM_FALLBACKS["budget"] += 1
             # the factorisation may depend on the lengths (fft 4M: one level of 128 when everything fits a quarter of it)
             ctx.fac = fac = _big.choose(mod.seqlen, max(u.shape[-1], k.shape[-1]), _TorchOps)
+            ctx.half = half = _big_half(mod, u.shape[0], max(u.shape[-1], k.shape[-1]), fac)
             try:
-                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, keep, None, fac)
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, keep, None, fac, half)
             except torch.cuda.OutOfMemoryError:
                 if not keep:
                     raise
                 SPECTRUM_FALLBACKS["oom"] += 1
-                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False, None, fac)
+                out, kf, kept = _big_forward(mod, u, k, pregate, postgate, False, None, fac, half)
         else:
             plan = mod._get_plan(u.device, mod._plan_seqlen)
             kf = mod._cached_kf(k) if mod.cache_kf and not k.requires_grad else None
@@ -647,7 +665,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if getattr(ctx, "kept_layout", None) is not None:
                 it = iter(ctx.saved_tensors[4 if ctx.gated else 2:])
                 kept = tuple(next(it) if present else None for present in ctx.kept_layout)
-            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len, kept, False, ctx.fac)
+            du, dk, dpre, dpost = _big_backward(ctx.mod, dout, u, kf, pregate, postgate, ctx.k_len, kept, False, ctx.fac, ctx.half)
             return du, dk.to(ctx.k_dtype), None, dpre, dpost
         plan = ctx.mod._get_plan(u.device, ctx.mod._plan_seqlen)
         B, H, L = u.shape
@@ -756,7 +774,7 @@ class FlashFFTConv(torch.nn.Module):
         implicit zero padding already skips the row traffic), and not for the frequency-sparse modules (their masks are defined on the
         seqlen-point spectrum)."""
         n = self.seqlen
-        if not (_FIT_FFT and self.fit_fft) or self._kf_keep is not None or n <= 32768:
+        if not (_FIT_FFT and getattr(self, "fit_fft", True)) or self._kf_keep is not None or n <= 32768:
             return n
         need = max(Lu + Lk - 1, 1)
         while n > 256 and n // 2 >= need:
@@ -764,10 +782,19 @@ class FlashFFTConv(torch.nn.Module):
         return n
 
     def _fitted_module(self, n):
-        m = self._fitted.get(n)
+        #  created lazily through getattr: a module unpickled / deep-copied from a version without the attribute still
+        # forwards; the children follow the parent's mode at every call and drop their cached k_f when the parent has none (cache_kf
+        # off, or invalidated), so that at most the sizes in use keep a k_f alive.  Not thread-safe: two threads that call ONE module in
+        # different modes race on the child's flags exactly as they would on the parent's own `training` attribute.
+        fitted = self.__dict__.setdefault("_fitted", {})
+        m = fitted.get(n)
         if m is None:
-            m = self._fitted[n] = FlashFFTConv(n, dtype=self.dtype, use_32_butterfly=self.use_32_butterfly)
+            m = fitted[n] = FlashFFTConv(n, dtype=self.dtype, use_32_butterfly=self.use_32_butterfly)
         m.training, m.save_spectrum, m.cache_kf, m.fit_fft = self.training, self.save_spectrum, self.cache_kf, False
+        if not self.cache_kf or self._kf_cache is None:
+            for c in fitted.values():
+                if c is not m:
+                    c._kf_cache = None
         return m
 
     def graphed_step(self, u, k, dout, pregate=None, postgate=None, warmup=3):

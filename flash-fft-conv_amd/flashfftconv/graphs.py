@@ -45,9 +45,20 @@ class GraphedStep:
                 for _ in range(max(1, warmup)):
                     self._eager()
             torch.cuda.current_stream(u.device).wait_stream(s)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, pool=pool):
-                y, grads = self._eager()
+            # whether the spectra are kept is decided HERE, by the budget test of the last warm-up step, and pinned for the capture: under
+            # capture hipMemGetInfo is off limits and an allocator OOM would poison the graph instead of falling back.  An OOM
+            # during the capture itself is fatal for the graph (RuntimeError from torch.cuda.graph), as for any captured region.
+            keep_mode = conv.save_spectrum
+            if keep_mode is True:
+                from . import conv as _C
+                n = ((u.shape[0] + 1) // 2) * u.shape[1] * conv.seqlen * (8 if self.gated else 4)
+                conv.save_spectrum = "always" if _C._spectrum_budget_ok(n, u.device, True) else False
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, pool=pool):
+                    y, grads = self._eager()
+            finally:
+                conv.save_spectrum = keep_mode
         finally:
             conv.train(was_training)
         self.y = y
@@ -64,7 +75,15 @@ class GraphedStep:
         """one graph launch on the current stream; results in self.y / self.du / self.dk (/ self.dpregate / self.dpostgate)"""
         self.graph.replay()
 
+    def _same(self, name, static, new):
+        if new is None or tuple(new.shape) != tuple(static.shape) or new.dtype != static.dtype:
+            raise RuntimeError(f"graphed step: {name} must be {tuple(static.shape)} {static.dtype} (the captured shapes), got "
+                               f"{None if new is None else (tuple(new.shape), new.dtype)}")      # (copy_ would broadcast silently: ADVICE r05)
+
     def __call__(self, u, k, dout, pregate=None, postgate=None):
+        self._same("u", self.u, u); self._same("k", self.k, k); self._same("dout", self.dout, dout)
+        if self.gated:
+            self._same("pregate", self.pregate, pregate); self._same("postgate", self.postgate, postgate)
         self.u.detach().copy_(u); self.k.detach().copy_(k); self.dout.copy_(dout)
         if self.gated:
             self.pregate.detach().copy_(pregate); self.postgate.detach().copy_(postgate)

@@ -347,13 +347,17 @@ class _BigOps:
         return self.C._big_forward(self.mod, u, None, pre, post, False, kf, self.fac)[0]
 
     def conv_keep(self, u, kf, pre, post):
-        keep = bool(self.mod.save_spectrum) and self.C._spectrum_budget_ok(
+        want = bool(self.mod.save_spectrum)
+        keep = want and self.C._spectrum_budget_ok(
             ((u.shape[0] + 1) // 2) * u.shape[1] * self.mod.seqlen * (8 if pre is not None else 4), u.device, self.mod.save_spectrum)
+        if want and not keep:
+            self.C.SPECTRUM_FALLBACKS["budget"] += 1      # counted like the single-rank module's
         try:
             out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, keep, kf, self.fac)
         except torch.cuda.OutOfMemoryError:      # same retry as the single-rank module
             if not keep:
                 raise
+            self.C.SPECTRUM_FALLBACKS["oom"] += 1
             out, _, kept = self.C._big_forward(self.mod, u, None, pre, post, False, kf, self.fac)
         return out, kept
 

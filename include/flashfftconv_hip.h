@@ -152,7 +152,12 @@ int ffc_kernel_ifft_grad_slabs(const ffc_plan* plan, const void* slabs, int64_t 
 /* `dtype` of the three level entry points: 0 bf16 / 1 fp16, optionally | 16: the LONG side is fp32 -- dir = 1: `in` is float, multiplied
  * by 2^e (e = bits 8..15 of dtype, the fp16 mode's prescale of the filter) and rounded once to the 16-bit type in the row load;
  * dir = 0: `out` is float (the 16-bit results widened).  The filter k and its gradient dk pass through the levels without cast
- * kernels this way.  Gates stay 16-bit. */
+ * kernels this way.  Gates stay 16-bit.
+ * | 32 (round 6, "half rows"): the long side is ONE REAL row per head (Bv == 1, npair == 1: a batch of one, the filter k, dk).  Its level
+ * rows are conjugate mirrors, x_{K-k0}[m] = W_Mi^m conj(x_k0[m]) with K = n0 (or R * 32) rows per head, so the short side holds the
+ * K / 2 + 1 rows k0 <= K / 2 only -- (2, Hin * (K / 2 + 1), Mi), pass c of an R-pass factor first its d <= 16 (c = 0) resp. d < 16 rows --
+ * and dir = 0 rebuilds the real output from them (weights 1, 2, .., 2, 1).  Half of the inner convolution's rows: what the reference's
+ * r2c / c2r kernels save at B = 1 (csrc/flashfftconv/monarch_cuda/kernels_bf16/monarch_cuda_shared_r2r_bf16.h:92-239). */
 int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int dtype, int dir, const void* in, void* out,
                    const void* gate, int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale,
                    void* stream);

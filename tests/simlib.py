@@ -133,7 +133,12 @@ class SimOps:
     def empty_f32(self, Bp, Hx, n):
         return np.full((Bp, Hx, n), np.nan, np.float32)
 
+    half = False         # one REAL row per head on the long side: the levels keep the rows k0 <= K / 2 only (csrc/ffc_big.h BigArgs::half)
+
     def outer(self, dt, n0, fwd, inp, out, gate, bv, npair, Hin, mi, Llong, scale, lf32=None):
+        if self.half:
+            assert bv == 1 and npair == 1
+            dt = dt | 32
         if lf32 is not None:       # the library's dtype flags (csrc/ffc_k_big.hip decode_dtype)
             e = int(round(np.log2(lf32)))
             assert 2.0 ** e == lf32 and (inp if fwd else out).dtype == np.float32

@@ -568,3 +568,44 @@ def test_levels_read_fp32_filter_and_write_fp32_dk(N, fac, Lk, dt):
     if fac[0][0] in (64, 128):      # one launch per pass: passes c > 0 add to the stored fp32 rows (values of the 16-bit type, as before)
         pp_old = S.SimOps(); pp_old.one_launch = False; pp_old.LONG_F32 = False
         assert np.array_equal(BG.dk_from_pair(per_pass, N, y, H, Lk, fac), BG.dk_from_pair(pp_old, N, y, H, Lk, fac))
+
+
+@pytest.mark.parametrize("N,fac,L,gated", [(65536, ((16,), 4096), 30000, False), (131072, ((32,), 4096), 131072, True), (262144, ((64,), 4096), 131072, False),
+                                           (524288, ((128,), 4096), 100004, True)])
+def test_batch_of_one_keeps_half_of_the_level_rows(N, fac, L, gated):
+    """round 6 (csrc/ffc_big.h BigArgs::half): ONE real row per head on the long side (B = 1; the filter and dk always) -- the level's rows
+    k0 and K - k0 are conjugate mirrors, so the levels store / read the K / 2 + 1 rows k0 <= K / 2 only and the inner kernel convolves half
+    as many.  Forward (gated, ragged) and dk against the oracle, and against the full-row form of the same run (equal to rounding)."""
+    from flashfftconv import bigfft as BG
+    rng = np.random.default_rng(N + L)
+    dt, H, B, M = 0, 2, 1, fac[1]
+    K = fac[0][0]
+    full, half = S.SimOps(), S.SimOps()
+    half.half = True
+    u, g1, g2, d = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.05).astype(np.float32)
+    ub, g1b, g2b, db = (S.to_bits(x, dt) for x in (u, g1, g2, d))
+    outs, dks = [], []
+    for ops in (full, half):
+        kf = BG.kernel_fft(ops, dt, N, k, H, L, fac)
+        x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None, fac)
+        rows = K // 2 + 1 if ops.half else K
+        assert x.shape == (2, H * rows, M) and kf.shape[0] == H * rows
+        y = ops.conv(dt, M, x, kf, False)
+        out = np.zeros_like(ub)
+        BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None, None, fac)
+        outs.append(S.from_bits(out, dt))
+        xd = BG.levels_forward(ops, dt, N, db, B, H, L, None, fac)
+        xu = BG.levels_forward(ops, dt, N, ub, B, H, L, None, fac)
+        dks.append(BG.dk_from_slabs(ops, N, ops.dkf(dt, M, xd, xu), xu.shape[0], H, L, None, fac))
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype="bf16") if gated else O.ref_fft_conv(q(u, dt), k, N)
+    _, dkref = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(outs[1], ref) < 1.5e-2 and rel(dks[1], dkref) < 1.5e-2
+    assert rel(outs[1], outs[0].astype(np.float64)) < 1e-2 and rel(dks[1], dks[0].astype(np.float64)) < 1e-2
+    if K > 32:      # one launch per pass (ffc_outer_pass_r) == all passes in one launch (ffc_outer_pass_all): the forward rows bit for bit
+        per_pass = S.SimOps(); per_pass.half = True; per_pass.one_launch = False
+        xa = BG.levels_forward(half, dt, N, ub, B, H, L, None, fac)
+        assert np.array_equal(xa, BG.levels_forward(per_pass, dt, N, ub, B, H, L, None, fac))
+        out2 = np.zeros_like(ub)
+        BG.levels_inverse(per_pass, dt, N, half.conv(dt, M, xa, BG.kernel_fft(half, dt, N, k, H, L, fac), False), out2, B, H, L, None, None, fac)
+        assert rel(S.from_bits(out2, dt), O.ref_fft_conv(q(u, dt), k, N)) < 1.5e-2
