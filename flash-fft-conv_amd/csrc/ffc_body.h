@@ -2435,140 +2435,6 @@ struct Body {
     }
   }
 
-  // ------------------------------------------------------------------ single-tile sizes: the NEXT tile in flight (round 6)
-  // fft <= 1024: one wave = one tile of G pairs, persistent workgroups.  A wave's job is a strictly serial chain -- row loads (+ gates), LDS,
-  // four DFT stages, stores -- and with 153 .. 163 VGPRs only ONE workgroup (8 waves) is resident per CU: while a tile is transformed the
-  // wave has nothing in flight, and the short-sequence launches ran at 2 .. 3 TB/s (12 GB/s per CU: latency x concurrency, not bandwidth;
-  // VERDICT r05 weak #8).  Here the wave walks ITS tiles across the jobs of its workgroup and requests the next tile's rows, input gate and
-  // k_f tile before it transforms the current one (and the current output gate before the transform instead of behind it): + 64 registers
-  // (2 waves per SIMD either way), one more tile's loads in flight per wave.  16-byte path only; ragged / misaligned calls keep conv_job.
-  struct TileIn { RowRegs X, G; KfRegs kf; };
-  template <int NC>
-  static FFC_FN void rows_load_of(const ConvArgs& a, const void* base, int64_t sb, int h, int pq, RowRegsT<NC>& X) {
-    const i32 lane = B::opaque(B::lane());
-#pragma unroll
-    for (int ii = 0; ii < NC; ii++) {
-      i32 idx = lane + ii * 64;
-      i32 row = idx / CPR, m = (idx % CPR) * 8;
-#pragma unroll
-      for (int pl = 0; pl < 2; pl++) {
-        i32 b = (row + pq * GEO::G) * 2 + pl;
-        X.v[ii][pl] = gload8_rows((const uint16_t*)base, b, h, a, sb, m, 1, b < a.B);
-      }
-    }
-  }
-  static FFC_FN void tile_request(const ConvArgs& a, int h, int q, TileIn& t) {
-    load_kf(a, h, 0, t.kf);
-    rows_load_of<NCH>(a, a.u, a.sbu, h, q, t.X);
-    if (a.pregate) rows_load_of<NCH>(a, a.pregate, a.sbg, h, q, t.G);
-  }
-  // (x) input gate, swizzle, write to E (rows_store for rows and gates that are already in registers)
-  static FFC_FN void rows_store_pre(const ConvArgs& a, Unit un, const TileIn& t) {
-    const i32 lane = B::opaque(B::lane());
-    const bool hasg = a.pregate != nullptr;
-#pragma unroll
-    for (int ii = 0; ii < NCH; ii++) {
-      i32 idx = lane + ii * 64;
-      i32 row = idx / CPR, m = (idx % CPR) * 8;
-      pred sw;
-      i32 off = pair_off(row, m, &sw) + un.eb;
-#pragma unroll
-      for (int pl = 0; pl < 2; pl++) {
-        U4 v = t.X.v[ii][pl];
-        if (hasg) v = mul4(v, t.G.v[ii][pl]);
-        U4 o;
-        o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
-        o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
-        B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
-      }
-    }
-  }
-  // E -> (x) output gate (already in registers: P) -> global
-  static FFC_FN void rows_out_pre(const ConvArgs& a, int h, int pq, Unit un, const RowRegs& P, bool hasp) {
-    const i32 lane = B::opaque(B::lane());
-#pragma unroll
-    for (int i = 0; i < NCH; i++) {
-      i32 idx = lane + i * 64;
-      i32 row = idx / CPR, m = (idx % CPR) * 8;
-      pred sw;
-      i32 off = pair_off(row, m, &sw) + un.eb;
-#pragma unroll
-      for (int pl = 0; pl < 2; pl++) {
-        U4 o = B::lds_r128(off + pl * GEO::PLANE);
-        U4 v;
-        v.x = B::sel(sw, o.z, o.x); v.y = B::sel(sw, o.w, o.y);
-        v.z = B::sel(sw, o.x, o.z); v.w = B::sel(sw, o.y, o.w);
-        if (hasp) v = mul4(v, P.v[i][pl]);
-        i32 b = (row + pq * GEO::G) * 2 + pl;
-        gstore8_rows((uint16_t*)a.y, b, h, a, a.sby, m, 1, b < a.B, v);
-      }
-    }
-  }
-  struct TileCur { int id, it, h, q; bool ok; };
-  // first tile of this wave at or behind (id, it) in the workgroup's job sequence id, id + nwg, ...
-  static FFC_FN void tile_seek(const ConvArgs& a, int u, int nwg, int total, TileCur& c) {
-    c.ok = false;
-    while (c.id < total) {
-      int h, chunk;
-      if (job_of(c.id, a.H, a.nchunk, &h, &chunk)) {
-        const int p0 = chunk * a.ppc;
-        int p1 = p0 + a.ppc;
-        if (p1 > a.npair) p1 = a.npair;
-        const int q0 = p0 / GEO::G, q1 = (p1 + GEO::G - 1) / GEO::G;
-        const int q = q0 + c.it * GEO::UPW + u;
-        if (q < q1) { c.h = h; c.q = q; c.ok = true; return; }
-      }
-      c.id += nwg; c.it = 0;
-    }
-  }
-  template <bool SZ>
-  static FFC_FN void conv_small(const ConvArgs& a, int wg0, int nwg) {
-    static_assert(!GEO::OUTER, "single-tile sizes");
-    const int total = ((a.H + 7) & ~7) * a.nchunk;
-    if (!a.fast || a.aux_in) {        // element-wise accesses: the job loop without the pipeline
-      for (int id = wg0; id < total; id += nwg) {
-        int h, chunk;
-        if (job_of(id, a.H, a.nchunk, &h, &chunk)) conv_job<false, false, SZ>(a, h, chunk);
-      }
-      return;
-    }
-    const int u = B::wave();
-    Unit un;
-    un.wq = 0; un.eb = u * GEO::EBYTES;
-    InnerRegs R;
-    load_inner(R, un);
-    TileCur c;
-    c.id = wg0; c.it = 0;
-    tile_seek(a, u, nwg, total, c);
-    TileIn t;
-    if (c.ok) tile_request(a, c.h, c.q, t);
-#pragma unroll 1
-    while (c.ok) {
-      TileCur n = c;
-      n.it++;
-      tile_seek(a, u, nwg, total, n);
-      rows_store_pre(a, un, t);
-      const KfRegs kf = t.kf;
-      RowRegs P;
-      const bool hasp = a.postgate != nullptr;
-      if (hasp) rows_load_of<NCH>(a, a.postgate, a.sbp, c.h, c.q, P);
-      if (n.ok) tile_request(a, n.h, n.q, t);          // in flight under this tile's transform and stores
-      B::lds_fence();
-      inner_tile<false, SZ>(a, 0, R, un, kf, nullptr, SZ ? z_slot_small(a.zsave, c.h, a.npair, c.q, 1, 0) : nullptr);
-      B::lds_fence();
-      if constexpr (SZ) {
-        if (a.yraw) {      // output before the postgate multiply (dpostgate = dout * this)
-          ConvArgs ar = a;
-          ar.y = a.yraw; ar.postgate = nullptr; ar.sby = (int64_t)a.H * a.L;
-          rows_out_pre(ar, c.h, c.q, un, P, false);
-        }
-      }
-      rows_out_pre(a, c.h, c.q, un, P, hasp);
-      B::lds_fence();
-      c = n;
-    }
-  }
-
   // ------------------------------------------------------------------ workgroup entry: conv
   // Workgroup handles head h and one chunk of that head's pairs, UPW units at a time.
   // HALF is chosen by the launcher: 32-point outer digit and L <= N/2

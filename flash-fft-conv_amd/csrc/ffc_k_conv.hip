@@ -27,9 +27,12 @@ __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) vo
   } else if constexpr (!GEO::OUTER) {
     // single-tile sizes (fft <= 1024): persistent workgroups too (two per CU): a job is one tile per wave, copying the plan
     // tables to LDS for every job cost as much as the job
-    // round 6: every wave keeps its next tile's rows, gate and k_f in flight while it transforms the current one (Body::conv_small)
     BD::setup_tables(a.tab, a.t);
-    BD::template conv_small<SZ>(a, blockIdx.x, gridDim.x);
+    const int total = ((a.H + 7) & ~7) * a.nchunk;
+    for (int id = blockIdx.x; id < total; id += gridDim.x) {
+      int h, chunk;
+      if (map_id(id, a.H, a.nchunk, &h, &chunk)) BD::template conv_job<HALF, false, SZ>(a, h, chunk);
+    }
   } else {
     int h, chunk;
     if (!map_block(a.H, a.nchunk, &h, &chunk)) return;

@@ -79,15 +79,6 @@ FFC_HD inline __attribute__((always_inline)) I e_off(I row, I m) {
   return row * (GEO::Mi * 2) + (n2 * GEO::CR + (cw ^ sig)) * 8 + (m & 3) * 2;
 }
 
-// Persistent workgroups walk the (head, chunk) jobs: job id -> (head, chunk), ids land on XCD (id % 8) and all chunks of a head stay on one XCD
-// (the same map as ffc_dev.h map_id, here for the backend-independent body: Body::conv_small)
-FFC_HD inline bool job_of(int id, int H, int nchunk, int* h, int* chunk) {
-  const int xcd = id & 7, s = id >> 3;
-  *h = xcd + 8 * (s / nchunk);
-  *chunk = s % nchunk;
-  return *h < H;
-}
-
 // Internal ("Monarch order") k_f layout: per h, NT tiles of 1024 complex; position
 //   ((tau*8 + rho)*32 + U)*4 + v   with V = 4*rho + v = sV*N3 + k3, U = sU*N2 + k2.
 // Returns the natural frequency index f held at that position.

@@ -341,18 +341,6 @@ static void run_wg(int nwaves, int lds_bytes, F fn) {
 
 template <class GEO, int DT>
 static void sim_conv_t(const ConvArgs& a) {
-  if constexpr (!GEO::OUTER) {
-    if (a.R <= 1) {      // single-tile sizes: persistent workgroups, the next tile in flight (conv_kernel -> Body::conv_small); 3 of them here
-      const int nwg = 3;
-      for (int wg = 0; wg < nwg; wg++)
-        run_wg(GEO::WGW, GEO::LDS_BYTES, [&]() {
-          Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
-          if (a.zsave) Body<SimB, GEO, DT>::template conv_small<true>(a, wg, nwg);
-          else Body<SimB, GEO, DT>::template conv_small<false>(a, wg, nwg);
-        });
-      return;
-    }
-  }
   for (int h = 0; h < a.H; h++)
     for (int c = 0; c < a.nchunk; c++) {
       if constexpr (GEO::N == 32768) {
