@@ -40,7 +40,7 @@ MFMA_FLOP = 2 * 32 * 32 * 16  # one v_mfma_f32_32x32x16_bf16
 # small JSON line per row BEFORE the contract line, the complete object is written to a side file, and the contract line holds
 # the contract keys plus a few numbers per table row -- asserted below LINE_LIMIT bytes.
 LINE_LIMIT = 4096
-ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "alg_bytes", "frac_hbm", "frac_executed")
+ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "frac_traffic", "launch_ms", "alg_bytes", "frac_hbm", "frac_executed")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "host_cpus")
 
 
@@ -483,18 +483,21 @@ def main():
     # the backward kernel on saved spectra executes one forward half + one inverse half per pair
     mf_bwd_saved = mf_bwd - 32 * (4 + 16)
     roof_bwd = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF,ZM=1> on saved spectra: du + dk in one launch (dk_f stays in the accumulation registers and is inverted by the same workgroup; the recomputing form is the ZM=0 instantiation)", mf_bwd_saved, dense_bwd, bwd_bytes,
-                    kt_step["conv_bwd_k"], prof_traffic("r05_pmc_bwd_kernel.txt", "traffic") or prof_traffic("r04_pmc_bwd_kernel.txt", "traffic"))
+                    kt_step["conv_bwd_k"], prof_traffic("r06_pmc_bwd_kernel.txt", "traffic") or prof_traffic("r05_pmc_bwd_kernel.txt", "traffic"))
     roof_bwd["launch_ms_isolated_loop"] = kt["conv_bwd_k"] * 1e3
     roof_bwd["launch_ms_without_dk_tail"] = kt_step["bwd_fused_saved"] * 1e3      # + dk_ifft as its own launch (round 3 form)
     roof_bwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_read": npair * N * 4, "u_not_read_any_more": -B * H * L * 2}
     roof_fwd = roof("conv_kernel<Geo<32,32,32>,bf16,HALF,SZ> (training forward: k -> k_f of the head, convolution, stores the spectra)", mf_fwd, dense_fwd, fwd_bytes,
-                    kt_step["conv_fwd_k"], prof_traffic("r05_pmc_conv_kernel.txt", "traffic") or prof_traffic("r04_pmc_conv_kernel.txt", "traffic"))
+                    kt_step["conv_fwd_k"], prof_traffic("r06_pmc_conv_kernel.txt", "traffic") or prof_traffic("r05_pmc_conv_kernel.txt", "traffic"))
     roof_fwd["launch_ms_isolated_loop"] = kt["conv_fwd_k"] * 1e3
     roof_fwd["launch_ms_without_kfft_head"] = kt_step["conv_fwd_save"] * 1e3      # + kfft as its own launch (round 3 form)
     roof_fwd["extra_bytes_not_in_alg_bytes"] = {"saved_spectra_write": npair * N * 4}
     for r in (roof_bwd, roof_fwd):      # bytes the kernel really has to move (incl. the spectra) vs the profiled traffic
         r["bytes_to_move"] = r["alg_bytes"] + sum(r["extra_bytes_not_in_alg_bytes"].values())
         r["traffic_over_bytes_to_move"] = round(r["traffic"] / r["bytes_to_move"], 3) if r["traffic"] else None
+        # the same launch time against the bytes that REALLY cross the fabric (profiled traffic: the saved spectra and the per-pair k_f
+        # re-reads included): the memory system's view of the kernel, next to `frac` = the algorithmic bytes of SURVEY 8(d)
+        r["frac_traffic"] = r["traffic"] / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if r["traffic"] else None
     roof_bwd_rc = roof("bwd_kernel<Geo<32,32,32>,bf16,HALF> recomputing FFT(u) (save_spectrum = False)", mf_bwd, dense_bwd, bwd_bytes,
                        kt["bwd_fused"], prof_traffic("r02_pmc_bwd_kernel.txt", "traffic"))
     # N > 1: the contract value is the FIXED problem (strong), the weak-scaled job rides beside it
