@@ -78,7 +78,7 @@ pmc("b", "bwd_kernel", "r06_pmc_bwd_kernel.txt", "benchmarks/prof_step_kernels.p
 pg = f"{O}/pytest_gpu.txt"
 if os.path.exists(pg):
     keep = [l for l in open(pg) if " passed" in l or " failed" in l or l.startswith("real")]
-    open(f"{P}/r06_pytest_gpu.txt", "w").write("# python -m pytest tests -m gpu -x -q on the final round-5 code (benchmarks/measure_r06.sh)\n" + "".join(keep))
+    open(f"{P}/r06_pytest_gpu.txt", "w").write("# python -m pytest tests -m gpu -x -q on the final round-6 code (benchmarks/measure_r06.sh)\n" + "".join(keep))
 
 rv = f"{O}/reference_verbatim.log"
 if os.path.exists(rv):

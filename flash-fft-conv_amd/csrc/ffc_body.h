@@ -1479,13 +1479,20 @@ struct Body {
   // the single-pass tables (HostPlan tabs.ipass, copied by setup_tables_ipass).
   static constexpr int IPASS_BYTES = 2 * 6144 + 2 * 8192;
   static constexpr int L_IPASS = GEO::LDS_BYTES;
-  struct InnerPass { Mat Fa, Finv; CT16 tw; int tw2_off; };
+  struct InnerPass { Mat Fa, Finv; CT16 tw; int tw2_off; int base; };
   static FFC_FN void load_inner_pass(InnerPass& ip, int k0) {
     const int base = L_IPASS + k0 * IPASS_BYTES;
     lds_mat(ip.Fa, base);
     lds_mat(ip.Finv, base + 6144);
     lds_ct16(ip.tw, base + 12288);
     ip.tw2_off = base + 12288 + 8192;
+    ip.base = base;
+  }
+  // lean form (IPL, round 6): only the LDS offsets; the pass's two matrices and its twiddle table are read from LDS where they are used
+  // (tile_fwd / tile_inv <.., IPL>).  The backward of fft 2048 kept all 80 registers of a pass next to its dk_f sums and spilled 34 - 43 of them.
+  static FFC_FN void load_inner_pass_lean(InnerPass& ip, int k0) {
+    ip.base = L_IPASS + k0 * IPASS_BYTES;
+    ip.tw2_off = ip.base + 12288 + 8192;
   }
   static FFC_FN void setup_tables_ipass(const uint8_t* tab, const PlanTabs& t, int R) {
     for (int k0 = 0; k0 < R; k0++) copy_tab(tab + t.ipass[k0], L_IPASS + k0 * IPASS_BYTES, IPASS_BYTES);
@@ -1541,7 +1548,7 @@ struct Body {
   // stage-a matrices.  Geo<32,32,32>, single pass.  `fold` = plan blob + PlanTabs::fold.
   // FFC_FOLD_TW (ffc_plan.h): 1 = the forward kernels of fft 16384 (default), 2 = also fft 32768 (forward + saved-spectra backward)
   static constexpr bool CAN_FOLD = ((FFC_FOLD_TW >= 1 && GEO::N1 == 16) || (FFC_FOLD_TW >= 2 && GEO::N1 == 32)) && GEO::N2 == 32 && GEO::N3 == 32;
-  template <bool TWR = true, bool IP = false, bool FOLD = false>
+  template <bool TWR = true, bool IP = false, bool FOLD = false, bool IPL = false>
   static FFC_FN void tile_fwd(int tau, const InnerRegs& R, Unit un, A16& re, A16& im, const InnerPass* ip = nullptr, const uint8_t* fold = nullptr,
                               const Mat2* fa_pre = nullptr) {
     if constexpr (FOLD) {
@@ -1565,7 +1572,12 @@ struct Body {
     load_tile_op(tau, op, un, R);
     // stage a: contract n2 (A-form) -> [V=(sV,n3) regs][U'=(sU,k2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
-    if constexpr (IP) {
+    if constexpr (IP && IPL) {
+      Mat Fa;
+      lds_mat(Fa, ip->base);
+      cmm<false, true>(re, im, op, Fa);
+      cmul_lds<false>(re, im, ip->base + 12288);
+    } else if constexpr (IP) {
       cmm<false, true>(re, im, op, ip->Fa);
       cmul(re, im, ip->tw);
     } else {
@@ -1588,7 +1600,7 @@ struct Body {
     }
   }
   // inverse half: spectrum tile (same layout) -> E tile, incl. the outer inverse twiddle
-  template <bool TWR = true, bool RP = false, bool IP = false, bool FOLD = false>
+  template <bool TWR = true, bool RP = false, bool IP = false, bool FOLD = false, bool IPL = false>
   static FFC_FN void tile_inv(float s_inv, int tau, const InnerRegs& R, Unit un, A16& re, A16& im, int dbg = 0, Pass ps = Pass(),
                               const InnerPass* ip = nullptr, const uint8_t* fold = nullptr, const Mat2* g_pre = nullptr) {
     const i32 lane = B::opaque(B::lane());
@@ -1646,7 +1658,11 @@ struct Body {
     to_op(re, im, op);
     // inverse stage a: contract k2 (A-form, conj) -> [V'' regs][U''=(sU,n2) lanes]
     re = B::a16_zero(); im = B::a16_zero();
-    if constexpr (IP) cmm<true, true>(re, im, op, ip->Finv);
+    if constexpr (IP && IPL) {
+      Mat Fi;
+      lds_mat(Fi, ip->base + 6144);
+      cmm<true, true>(re, im, op, Fi);
+    } else if constexpr (IP) cmm<true, true>(re, im, op, ip->Finv);
     else cmm<true, true>(re, im, op, R.F2);
     // outer inverse twiddle s_inv * W_N^{-(n2*N3+n3)*k1}, generated on the fly (v_sin/v_cos take
     // revolutions; the integer phase m*k1 mod N is exact), so no table traffic in the tile loop
@@ -2465,6 +2481,99 @@ struct Body {
       if constexpr (RP) {
         // multi-pass inner-only form (fft 2048 on the 32 x 32 kernel): G == 1, the R passes of a pair back to back
         static_assert(GEO::G == 1, "inner-only multi-pass: one pair per tile");
+        // Round 6: rows that fit one block (L <= 1024: the padded case, sum_n0 has one term) -- the pair's rows are loaded ONCE and stay
+        // in registers for every pass, and the passes' outputs are summed in registers and stored ONCE.  Before, every pass loaded the
+        // rows again and passes k0 > 0 read-modify-wrote the output rows (and the pre-postgate copy of the gated training forward):
+        // per pair 2 loads of u, 2 stores + 1 load of y instead of one each -- a third of the launch's traffic at fft 2048, whose
+        // kernels run at the memory system's rate (profiles/r06_ab_small_pipe.txt).  Same arithmetic in the same order: bit-identical
+        // (FFC_IP_MERGE=0: the per-pass form, tests/test_build_switches.py).
+#ifndef FFC_IP_MERGE
+#define FFC_IP_MERGE 1
+#endif
+        if (FFC_IP_MERGE != 0 && a.fast && a.L <= GEO::N && !a.aux_in) {
+          const i32 lane = B::opaque(B::lane());
+#pragma unroll 1
+          for (int it = 0; it < iters; it++) {
+            const int q = q0 + it * GEO::UPW + u;
+            if (q >= q1) continue;
+            RowRegs X, Y;
+            rows_load<NCH>(a, h, q, un, X);
+            if (a.pregate) {
+              RowRegs G;
+#pragma unroll
+              for (int ii = 0; ii < NCH; ii++) {
+                i32 idx = lane + ii * 64;
+                i32 m = (idx % CPR) * 8;
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                  i32 b = (idx / CPR + q * GEO::G) * 2 + pl;
+                  G.v[ii][pl] = gload8_rows((const uint16_t*)a.pregate, b, h, a, a.sbg, m, 1, b < a.B);
+                }
+              }
+#pragma unroll
+              for (int ii = 0; ii < NCH; ii++)
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) X.v[ii][pl] = mul4(X.v[ii][pl], G.v[ii][pl]);
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < a.R; k0++) {
+              InnerPass ip;
+              load_inner_pass(ip, k0);
+              KfRegs kf;
+              load_kf(a, h * a.R + k0, 0, kf);
+#pragma unroll
+              for (int ii = 0; ii < NCH; ii++) {
+                i32 idx = lane + ii * 64;
+                pred sw;
+                i32 off = pair_off(idx / CPR, (idx % CPR) * 8, &sw) + un.eb;
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                  const U4& v = X.v[ii][pl];
+                  U4 o;
+                  o.x = B::sel(sw, v.z, v.x); o.y = B::sel(sw, v.w, v.y);
+                  o.z = B::sel(sw, v.x, v.z); o.w = B::sel(sw, v.y, v.w);
+                  B::lds_w128(off + pl * GEO::PLANE, o, B::ptrue());
+                }
+              }
+              B::lds_fence();
+              inner_tile<true, SZ>(a, 0, R, un, kf, &ip, SZ ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
+              B::lds_fence();
+#pragma unroll
+              for (int ii = 0; ii < NCH; ii++) {
+                i32 idx = lane + ii * 64;
+                pred sw;
+                i32 off = pair_off(idx / CPR, (idx % CPR) * 8, &sw) + un.eb;
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                  U4 o = B::lds_r128(off + pl * GEO::PLANE);
+                  U4 v;
+                  v.x = B::sel(sw, o.z, o.x); v.y = B::sel(sw, o.w, o.y);
+                  v.z = B::sel(sw, o.x, o.z); v.w = B::sel(sw, o.y, o.w);
+                  // y[m] (+)= y_k0[m] (n0 = 0: no rotation), fp32 sum rounded once, as rows_out_rp
+                  if (k0 == 0) Y.v[ii][pl] = v;
+                  else Y.v[ii][pl] = add4(Y.v[ii][pl], v, 1.0f);
+                }
+              }
+              B::lds_fence();
+            }
+#pragma unroll
+            for (int ii = 0; ii < NCH; ii++) {
+              i32 idx = lane + ii * 64;
+              i32 m = (idx % CPR) * 8;
+#pragma unroll
+              for (int pl = 0; pl < 2; pl++) {
+                i32 b = (idx / CPR + q * GEO::G) * 2 + pl;
+                U4 v = Y.v[ii][pl];
+                if constexpr (SZ) {
+                  if (a.yraw) gstore8_rows((uint16_t*)a.yraw, b, h, a, (int64_t)a.H * a.L, m, 1, b < a.B, v);      // output before the postgate
+                }
+                if (a.postgate) v = mul4(v, gload8_rows((const uint16_t*)a.postgate, b, h, a, a.sbp, m, 1, b < a.B));
+                gstore8_rows((uint16_t*)a.y, b, h, a, a.sby, m, 1, b < a.B, v);
+              }
+            }
+          }
+          return;
+        }
 #pragma unroll 1
         for (int it = 0; it < iters * a.R; it++) {
           const int q = q0 + (it / a.R) * GEO::UPW + u;

@@ -8,6 +8,9 @@
 // Pair packing keeps working for dk: with z_u = u_a + i u_b and z_d = d_a + i d_b,
 //   Re iFFT( Z_d * conj(Z_u) ) = corr(d_a,u_a) + corr(d_b,u_b).
 #pragma once
+#ifndef FFC_IP_LEAN
+#define FFC_IP_LEAN 1      // 0: the pass's tables resident in 80 registers (round 5: 34 - 43 registers spilled; A/B builds)
+#endif
 #ifndef FFC_KF_LATE
 #define FFC_KF_LATE 0
 #endif
@@ -358,7 +361,7 @@ struct Modes : Body<B, GEO, DT> {
             k_rows_in_rp(a, unit_id, un, ps);
             B::lds_fence();
             A16 re, im;
-            BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+            BD::template tile_fwd<true, true, false, FFC_IP_LEAN != 0>(0, R, un, re, im, &ip);
             kf_store_flat(a, unit_id * a.R + k0, re, im, a.H * a.R);
             B::lds_fence();
           }
@@ -975,12 +978,13 @@ struct Modes : Body<B, GEO, DT> {
         BD::setup_tables_ipass(a.tab, a.t, a.R);
         const int q0 = p0, q1 = p1;
         const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
-        BD::load_inner(R, un);
+        BD::template load_inner<false>(R, un);      // (the single-pass twiddle table is not used by the pass forms)
 #pragma unroll 1
         for (int k0 = 0; k0 < a.R; k0++) {
           Pass ps; ps.k0 = k0; ps.R = a.R;
           InnerPass ip;
-          BD::load_inner_pass(ip, k0);
+          if constexpr (FFC_IP_LEAN != 0) BD::load_inner_pass_lean(ip, k0);     // round 6: matrices / twiddles of the pass from LDS at their use
+          else BD::load_inner_pass(ip, k0);
           A16 wre = B::a16_zero(), wim = B::a16_zero();
 #pragma unroll 1
           for (int it = 0; it < iters; it++) {
@@ -990,12 +994,12 @@ struct Modes : Body<B, GEO, DT> {
               A16 re, im;
               BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
               B::lds_fence();
-              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              BD::template tile_fwd<true, true, false, FFC_IP_LEAN != 0>(0, R, un, re, im, &ip);
               z_pack(re, im, zv);
               B::lds_fence();
               BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
               B::lds_fence();
-              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              BD::template tile_fwd<true, true, false, FFC_IP_LEAN != 0>(0, R, un, re, im, &ip);
               w_add(wre, wim, zv, re, im);
               B::lds_fence();
             }
@@ -1333,12 +1337,16 @@ struct Modes : Body<B, GEO, DT> {
         if constexpr (SETUP) BD::setup_tables_ipass(a.tab, a.t, a.R);
         const int q0 = p0, q1 = p1;
         const int iters = (q1 - q0 + GEO::UPW - 1) / GEO::UPW;
-        BD::load_inner(R, un);
+        BD::template load_inner<false>(R, un);      // (the single-pass twiddle table is not used by the pass forms)
 #pragma unroll 1
         for (int k0 = 0; k0 < a.R; k0++) {
           Pass ps; ps.k0 = k0; ps.R = a.R;
           InnerPass ip;
-          BD::load_inner_pass(ip, k0);
+          // round 6: the pass's two matrices and its twiddle table are read from LDS where they are used (tile_fwd / tile_inv <.., IPL>); with all
+          // 80 registers of a pass resident next to the dk_f sums this kernel spilled 34 - 43 registers into scratch memory inside the pair loop
+          // (fft 2048 backward 0.084 -> 0.062 ms at B16 H768, profiles/r06_ab_fft2048.txt)
+          if constexpr (FFC_IP_LEAN != 0) BD::load_inner_pass_lean(ip, k0);
+          else BD::load_inner_pass(ip, k0);
           A16 wre = B::a16_zero(), wim = B::a16_zero();
 #pragma unroll 1
           for (int it = 0; it < iters; it++) {
@@ -1354,19 +1362,19 @@ struct Modes : Body<B, GEO, DT> {
               } else {
                 BD::template rows_in_rp<BD::NCH>(av, h, q, un, ps);
                 B::lds_fence();
-                BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+                BD::template tile_fwd<true, true, false, FFC_IP_LEAN != 0>(0, R, un, re, im, &ip);
                 z_pack(re, im, zv);
                 B::lds_fence();
               }
               if (ad.aux_in && k0 == 0) BD::template rows_aux_rp<BD::NCH>(ad, h, q, un);      // dpost = dout * yraw, once per pair
               BD::template rows_in_rp<BD::NCH>(ad, h, q, un, ps);
               B::lds_fence();
-              BD::template tile_fwd<true, true>(0, R, un, re, im, &ip);
+              BD::template tile_fwd<true, true, false, FFC_IP_LEAN != 0>(0, R, un, re, im, &ip);
               if (d.zin) w_add_k(wre, wim, zk, re, im);
               else w_add(wre, wim, zv, re, im);
               kf_conj_mul(kf, re, im);
               B::lds_fence();
-              BD::template tile_inv<true, false, true>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
+              BD::template tile_inv<true, false, true, false, FFC_IP_LEAN != 0>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
               B::lds_fence();
               BD::template rows_out_rp<BD::NCH>(ao, h, q, un, ps);
               if (d.dpre) BD::template rows_out_rp<BD::NCH>(ap, h, q, un, ps);
@@ -1686,7 +1694,7 @@ struct Modes : Body<B, GEO, DT> {
             BD::load_inner_pass(ip, k0);
             A16 re, im;
             w_load(a, unit_id * a.R + k0, 0, re, im, a.R);
-            BD::template tile_inv<true, false, true>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
+            BD::template tile_inv<true, false, true, false, FFC_IP_LEAN != 0>(a.s_inv, 0, R, un, re, im, 0, Pass(), &ip);
             B::lds_fence();
             dk_rows_out_rp(a, unit_id, un, ps);
             B::lds_fence();

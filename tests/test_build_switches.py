@@ -11,7 +11,9 @@ PKG = os.path.join(os.path.dirname(HERE), "flash-fft-conv_amd")
 # round 5: FFC_OUTER_QUAD = 0 is the tile-pair form of phases A / C (4-byte LDS accesses), FFC_RP_FASTK = 0 the multi-pass backward with the
 # run-time access-width switch in every row access (the default launches a 16-byte-only instantiation on aligned tensors)
 # FFC_PK_GATE = 0: fp16 gate multiplies through fp32 (the packed fp16 multiply rounds the exact product once: the same bits)
-ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0", "-DFFC_PK_GATE=0"]
+# round 6: FFC_IP_MERGE = 0 is the fft-2048 forward with one row load / one read-modify-write of the output per PASS (the default keeps the pair's rows
+# and the passes' sum in registers: one load, one store)
+ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0", "-DFFC_PK_GATE=0", "-DFFC_IP_MERGE=0"]
 
 
 def _alt_sim():
@@ -27,7 +29,7 @@ def _alt_sim():
     return so
 
 
-CASES = [(256, 200, 5, 2, 1, True), (1024, 1024, 3, 2, 0, True), (2048, 1024, 4, 1, 0, True), (4096, 2048, 5, 1, 1, True),
+CASES = [(256, 200, 5, 2, 1, True), (1024, 1024, 3, 2, 0, True), (2048, 1024, 4, 1, 0, True), (2048, 1000, 3, 2, 1, False), (2048, 2048, 2, 1, 0, True), (4096, 2048, 5, 1, 1, True),
          (32768, 16384, 3, 1, 0, False), (32768, 9000, 2, 1, 0, True), (65536, 32768, 3, 1, 0, True), (65536, 40004, 1, 1, 1, False),
          (65536, 65536, 2, 1, 0, True), (131072, 65536, 1, 1, 0, False), (8192, 4096, 3, 1, 1, True), (16384, 16384, 2, 1, 0, False)]
 _SCRIPT = r'''
