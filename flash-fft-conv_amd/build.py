@@ -124,6 +124,32 @@ def check_load_runs(asm_path, rules):
         raise RuntimeError(f"{asm_path}: loads-in-flight audit: {bad[:4] if bad else 'no kernel matched the rules'}")
 
 
+# Register-spill audit (round 6).  The backward kernel of fft 1024 / 2048 had been spilling 34 - 43 registers into scratch memory inside its pair loop
+# since round 2, the BLH weight-gradient kernel of conv1d 66 - 77 (a missing __launch_bounds__), and nothing said so: fft 2048 backward -27 % once
+# the spills were gone (profiles/r06_ab_fft2048.txt).  Every translation unit is now compiled with -Rpass-analysis=kernel-resource-usage; the
+# per-kernel figures go to lib/resource_usage.txt and a kernel with more than SCRATCH_LIMIT bytes of scratch per lane fails the build (the few
+# kernels below it spill 2 - 8 registers once per job, outside their loops).
+SCRATCH_LIMIT = 64
+
+
+def parse_resource_usage(text):
+    import re
+    rows, cur = [], None
+    for line in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"fn": m.group(1)}
+            rows.append(cur)
+            continue
+        for key, name in (("VGPRs Spill", "spill"), (r"ScratchSize \[bytes/lane\]", "scratch"), ("AGPRs", "agprs"), ("VGPRs", "vgprs"),
+                          (r"Occupancy \[waves/SIMD\]", "occupancy"), (r"LDS Size \[bytes/block\]", "lds")):
+            m = re.search(key + r": (\d+)", line)
+            if m and cur is not None:
+                cur[name] = int(m.group(1))
+                break
+    return rows
+
+
 def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=None):
     """Compile every translation unit for gfx950 in parallel, then link the shared library.
     variant: tuning build with `extra_flags` under lib/variants/<name>/ (A/B runs: FFC_LIB=<that .so>)."""
@@ -158,10 +184,24 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
                 os.remove(marker)
             only = os.environ.get("FFC_VARIANT_ONLY")      # tuning builds: extra flags for one translation unit only
             fl = flags if (not only or f == only) else HIP_FLAGS
-            cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + ["-c", "-x", "hip", src, "-o", out]
+            is_hip = f.endswith(".hip")
+            cmd = [hipcc] + fl + (["-save-temps=obj"] if checked else []) + (["-Rpass-analysis=kernel-resource-usage"] if is_hip else []) + ["-c", "-x", "hip", src, "-o", out]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd, cwd=obj_dir)
+            r = subprocess.run(cmd, cwd=obj_dir, capture_output=True, text=True)
+            if r.returncode != 0:
+                sys.stderr.write(r.stderr[-8000:])
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            if is_hip:
+                rows = parse_resource_usage(r.stderr)
+                with open(os.path.join(obj_dir, stem + ".ru.txt"), "w") as fh:
+                    for k in rows:
+                        fh.write(f"{f} {k['fn']} vgprs {k.get('vgprs')} agprs {k.get('agprs')} scratch {k.get('scratch')} spill {k.get('spill')} "
+                                 f"occupancy {k.get('occupancy')}\n")
+                bad = [k for k in rows if (k.get("scratch") or 0) > SCRATCH_LIMIT]
+                if bad and not any(x.startswith("-DFFC_KO") for x in fl):
+                    os.remove(out)
+                    raise RuntimeError(f"{f}: register spills: " + "; ".join(f"{k['fn'][:90]} scratch {k['scratch']} B/lane ({k.get('spill')} VGPRs)" for k in bad[:4]))
             if checked and not os.environ.get("FFC_SKIP_AGPR_CHECK"):      # (knock-out timing builds skip the check)
                 try:
                     if f in AGPR_CHECKED:
@@ -185,6 +225,12 @@ def build_hip(force=False, verbose=False, variant=None, extra_flags=(), srcs=Non
     objs = [o for o, _ in res]
     if force or any(ch for _, ch in res) or not os.path.exists(hip_so):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hip_so] + objs)
+    # per-kernel register / scratch figures of the library as built (one line per kernel)
+    with open(os.path.join(lib_dir, "resource_usage.txt"), "w") as fh:
+        for f in sorted(HIP_SRCS):
+            ru = os.path.join(obj_dir, os.path.splitext(f)[0] + ".ru.txt")
+            if os.path.exists(ru):
+                fh.write(open(ru).read())
     return hip_so
 
 

@@ -377,8 +377,10 @@ __global__ void blh_kernel(const typename El<TI>::S* __restrict__ u, const typen
 }
 
 // dw[k,d], dbias[d] for BLH: thread = V channels, block loops over a slab of (b,l) rows.
+// (launched with 64 threads: without the bound the compiler budgets for 1024-thread blocks = 128 registers and spilled 66 - 77 of this kernel's
+// 16 x 8 fp32 sums into scratch memory, hipcc -Rpass-analysis=kernel-resource-usage; round 6)
 template <int TI, bool FAST>
-__global__ void blh_wgrad_kernel(const typename El<TI>::S* __restrict__ dout, const typename El<TI>::S* __restrict__ u,
+__global__ __launch_bounds__(64) void blh_wgrad_kernel(const typename El<TI>::S* __restrict__ dout, const typename El<TI>::S* __restrict__ u,
                                  float* __restrict__ dw, float* __restrict__ dbias, int B, int D, int L, int Lout, int K, int P,
                                  int rows_per_block) {
   const int d0 = (blockIdx.x * blockDim.x + threadIdx.x) * V;
