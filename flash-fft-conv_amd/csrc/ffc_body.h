@@ -260,7 +260,7 @@ struct Body {
   }
   // apply a chain8p result to accumulator rows 8*half + {0..7}
   static FFC_FN void apply8(A16& re, A16& im, int half, const F2 (&tr)[4], const F2 (&ti)[4]) {
-#if defined(FFC_EXP_NOTWIDDLE) || (defined(FFC_KO) && (FFC_KO & 1))
+#if defined(FFC_KO) && (FFC_KO & 1)
     return;      // timing experiment only: results are wrong
 #endif
 #pragma unroll
@@ -380,10 +380,6 @@ struct Body {
     if constexpr (GEO::N3 != GEO::N2) tab_commit<6144>(GEO::L_F3, f3);
     if constexpr (GEO::TW2_SEP) tab_commit<8192>(GEO::L_TW2, tw2);
     if constexpr (GEO::HAS_SP) tab_commit<3072>(GEO::L_FS, fs);
-    if (B::wave() == 0) {      // tile counters of the dynamically scheduled phase B (64 bytes)
-      U4 z; z.x = B::uconst(0); z.y = B::uconst(0); z.z = B::uconst(0); z.w = B::uconst(0);
-      B::lds_w128(B::lane() * 16 + GEO::L_DYN, z, B::lane() < 4);
-    }
     B::barrier();
   }
   static FFC_FN void lds_mat(Mat& m, int off) {
@@ -2370,42 +2366,14 @@ struct Body {
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2_sp(a, hk, un.wq * GEO::TPW + tt, R, Fs, un);
         } else if constexpr (GEO::N3 == GEO::N2) {
-#ifndef FFC_DYN_TILES
-#define FFC_DYN_TILES 0
-#endif
-#if FFC_DYN_TILES
-          // (measured and NOT adopted, profiles/r04_ab_dyn_tiles.txt: forward +3 % at fft 32768 L = N/2, -3.5 % on the spectrum-saving
-          // forward at L = N, +-0 elsewhere -- the static split with wave priorities is already balanced to within a tile; and the
-          // one-wave-per-unit persistent kernel (fft 4096) must not use it: its jobs restart the counter parity.  Kept as a variant.)
-          // Dynamically scheduled phase B (round 4): the unit's NT tiles are handed out in pairs through an LDS counter instead of
-          // four fixed tiles per wave.  The two waves of a SIMD never run at the same rate (issue is oldest-first: profiles/
-          // r03_wave_priority.txt), so with a fixed split one of them finishes early and waits at the barrier; here the faster
-          // wave simply takes more tiles and all waves reach the barrier within one tile pair of each other.  Results do not
-          // depend on which wave computes a tile.  Two counters per unit, used alternately: the one the previous iteration used
-          // is reset here, behind the barrier that every wave passed after it last touched it.
-          uint8_t* const zsl = SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr;
-          const int cnt = GEO::L_DYN + (u * 2 + (it & 1)) * 4;
-          if (un.wq == 0) B::lds_w32(B::lane() * 0 + (GEO::L_DYN + (u * 2 + ((it + 1) & 1)) * 4), B::uconst(0));
-          if constexpr (GEO::NW > 1) {
-            int tt = B::lds_fetch_add(cnt, 2);
-#pragma unroll 1
-            while (tt < GEO::NT) {
-              const int nxt = B::lds_fetch_add(cnt, 2);
-              inner_tile2<RP, SZ>(a, hk, tt, R, un, ps, zsl);
-              tt = nxt;
-            }
-          } else {
-#pragma unroll 1
-            for (int tt = 0; tt < GEO::TPW; tt += 2) inner_tile2<RP, SZ>(a, hk, un.wq * GEO::TPW + tt, R, un, ps, zsl);
-          }
-#else
+          // (a dynamically scheduled phase B -- tiles handed out through an LDS counter -- was measured in round 4, +3 % / -3.5 %, and removed in
+          // round 6: profiles/r04_ab_dyn_tiles.txt)
 #pragma unroll 1
           for (int tt = 0; tt < GEO::TPW; tt += 2) {
             if (tt == 0) { FFC_PRIO(3) } else if (second) { FFC_PRIO(2) } else { FFC_PRIO(1) }
             inner_tile2<RP, SZ, FOLDF, HALF>(a, hk, un.wq * GEO::TPW + tt, R, un, ps,
                                 SZ ? (RP ? z_slot_rp(a.zsave, h, a.npair, p, ps.R, ps.k0) : z_slot(a.zsave, h, a.npair, p)) : nullptr);
           }
-#endif
         } else {
           KfRegs kf0;
           load_kf(a, h, un.wq * GEO::TPW, kf0);

@@ -193,13 +193,6 @@ struct DevB {
     if constexpr (NT) __builtin_amdgcn_global_load_lds(g, l, 4, 0, 2);
     else __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
   }
-  // wave-uniform fetch-and-add on an LDS word: one lane performs it, the old value is broadcast
-  static FFC_FN int lds_fetch_add(int off, int v) {
-    int r = 0;
-    if ((threadIdx.x & 63) == 0)
-      r = __hip_atomic_fetch_add((int*)__builtin_assume_aligned(ffc_smem + off, 4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return __builtin_amdgcn_readfirstlane(r);
-  }
   // 16-byte form: lane's 16 bytes at base[o16] -> LDS[lds_off + 16 * lane] (1 KB per wave instruction)
   template <bool NT>
   static FFC_FN void g2lds128(const void* base, i32 o16, int lds_off) {

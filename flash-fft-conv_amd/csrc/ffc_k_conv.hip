@@ -9,10 +9,6 @@ using namespace ffc;
 template <class GEO, int DT, bool HALF, bool SZ = false, bool SP = false>
 __global__ __launch_bounds__(GEO::WGW * 64, GEO::OUTER ? 2 : FFC_SMALL_WAVES) void conv_kernel(ConvArgs a) {
   using BD = Body<DevB, GEO, DT>;
-#if defined(FFC_SETPRIO)
-  // static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, "two waves per SIMD" item 4)
-  if (DevB::wave() >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   if constexpr (GEO::OUTER && GEO::NW == 1) {
     // One wave per unit (fft 4096): persistent workgroups, one per CU, walk the (head, chunk) jobs with a stride of
     // the grid (a multiple of 8, so a workgroup's heads stay on its XCD).  No phase of these units needs a

@@ -58,9 +58,7 @@ struct Geo {
   static constexpr int L_BASE = L_TW2 + (TW2_SEP ? 8192 : 0);
   static constexpr bool HAS_SP = OUTER && N2 == 32 && N3 == 32;    // frequency-sparse kernel variant (PlanTabs::mat_sp)
   static constexpr int L_FS = L_BASE;
-  // tile counters of the dynamically scheduled phase B (Body::outer_jobs, FFC_DYN_TILES): two per unit, used alternately
-  static constexpr int L_DYN = L_BASE + (HAS_SP ? 3072 : 0);
-  static constexpr int LDS_BYTES = L_DYN + 64;   // outer twiddles are generated on the fly (no tables)
+  static constexpr int LDS_BYTES = L_BASE + (HAS_SP ? 3072 : 0);   // outer twiddles are generated on the fly (no tables)
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
   static_assert(N2 == 16 || N2 == 32, "");
   static_assert(N3 == 16 || N3 == 32, "");

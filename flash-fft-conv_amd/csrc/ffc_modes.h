@@ -11,9 +11,6 @@
 #ifndef FFC_IP_LEAN
 #define FFC_IP_LEAN 1      // 0: the pass's tables resident in 80 registers (round 5: 34 - 43 registers spilled; A/B builds)
 #endif
-#ifndef FFC_KF_LATE
-#define FFC_KF_LATE 0
-#endif
 #include "ffc_body.h"
 
 namespace ffc {
@@ -833,24 +830,16 @@ struct Modes : Body<B, GEO, DT> {
   // second phase B of dkf / bwd: the tile loop stays rolled (an unrolled one lets the compiler merge the tiles
   // and spill); the resident accumulator of tile slot tt is selected by a wave-uniform switch so that the
   // accumulator registers are addressed statically.
-  // FFC_Z_PREFETCH (build switch, round-5 experiment): the spectrum tile of iteration tt + 1 is requested right behind the last use of
-  // tile tt's (the accumulation), so that it is in flight under this tile's inverse half and the next tile's forward half; k_f behind the
-  // transform (the FFC_KF_LATE placement): 16 loop-carried registers instead of the 32 that failed the accumulation-register audit in round 4
-#ifndef FFC_Z_PREFETCH
-#define FFC_Z_PREFETCH 0
-#endif
+  // (round 5 measured two re-orderings of this loop's loads -- the next tile's spectrum requested early, k_f behind the transform -- both +-0,
+  // profiles/r05_ab_zprefetch.txt / r05_ab_kf_late.txt; the switches were removed in round 6)
   template <bool WITH_DX, bool RP = false, bool ZSAVED = false>
   static FFC_FN void bwd_tiles(const ConvArgs& a, int h, Unit un, const InnerRegs& R, const void* zs, float* slab, bool first, WAcc& W,
                                Pass ps = Pass(), bool z_stream = false, bool second = false) {
-    // (fft 32768 geometry only: with it the one-wave-per-unit kernel of fft 4096 parks values in a0..a5, build.py check_agpr)
-    // (... and not the multi-pass or the recomputing kernels: their allocation reaches into a0..a11 with it)
-    constexpr bool PF = FFC_Z_PREFETCH != 0 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW) && GEO::N1 == 32 && GEO::N2 == 32 && GEO::N3 == 32;
     // folded outer twiddle (Body::tile_fwd / tile_inv <.., FOLD>): the saved-spectra backward of single-pass fft 32768, whose phase A ran
     // without the twiddle (Modes::bwd)
     constexpr bool FOLD = BD::CAN_FOLD && GEO::N1 == 32 && WITH_DX && !RP && ZSAVED && (WREG >= GEO::TPW);
     const uint8_t* fold = FOLD ? a.tab + a.t.fold : nullptr;
     typename BD::KfRegs zv;
-    if constexpr (PF) z_load(zs, un.wq * GEO::TPW, zv, z_stream || (a.flags & 4) != 0);
     // FOLD: every matrix is requested one stage ahead of its use; the next tile's first matrix behind this tile's last stage (16 loop-carried registers)
     typename BD::Mat2 fa;
     if constexpr (FOLD) BD::load_mat2_issue(fa, fold + (un.wq * GEO::TPW) * 6144, B::opaque(B::lane()));
@@ -862,11 +851,9 @@ struct Modes : Body<B, GEO, DT> {
         if (tt == GEO::TPW / 2) { if (second) B::template setprio<2>(); else B::template setprio<1>(); }
       }
 #endif
-      if constexpr (!PF) z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
+      z_load(zs, tau, zv, z_stream || (a.flags & 4) != 0);
       typename BD::KfRegs kf;
-      // FFC_KF_LATE=1 (build switch, OFF; measured in round 5: no effect, profiles/r05_ab_kf_late.txt): the k_f tile requested BEHIND the
-      // transform instead of next to the spectrum tile -- four load tuples instead of eight live across tile_fwd
-      constexpr bool KFL = FFC_KF_LATE != 0 || PF || FOLD;
+      constexpr bool KFL = FOLD;      // (folded-twiddle variant: the k_f tile requested behind the transform, its matrices take the registers)
       if constexpr (WITH_DX && !KFL) BD::load_kf(a, h, tau, kf);
       A16 re, im;
       if (WREG >= GEO::TPW || tt < WREG) {
@@ -877,10 +864,6 @@ struct Modes : Body<B, GEO, DT> {
           case 1: if constexpr (WREG > 1) w_acc_tile<1>(zv, re, im); break;
           case 2: if constexpr (WREG > 2) w_acc_tile<2>(zv, re, im); break;
           default: if constexpr (WREG > 3) w_acc_tile<3>(zv, re, im); break;
-        }
-        if constexpr (PF) {      // next tile's spectrum (clamped on the last iteration: a harmless re-read of this tile)
-          const int tn = tt + 1 < GEO::TPW ? tau + 1 : tau;
-          z_load(zs, tn, zv, z_stream || (a.flags & 4) != 0);
         }
       } else {
         WOld wold;

@@ -201,7 +201,6 @@ struct SimB {
     for (int i = 0; i < 64; i++) { chk(lds_off + 16 * i, 16); memcpy(L() + lds_off + 16 * i, (const uint8_t*)base + 16 * (int64_t)o16.v[i], 16); }
   }
   static void vm_wait0() {}
-  static int lds_fetch_add(int off, int v) { chk(off, 4); return __atomic_fetch_add((int*)(L() + off), v, __ATOMIC_SEQ_CST); }
   static void lds_w32p(const i32& off, const u32& v, const pred& p) {
     for (int i = 0; i < 64; i++) if (p.v[i]) { chk(off.v[i], 4); memcpy(L() + off.v[i], &v.v[i], 4); }
   }

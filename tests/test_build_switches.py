@@ -1,6 +1,6 @@
 """The build switches that select between two forms of the same arithmetic must not change a single bit (round 4's load-scheduling work:
 FFC_GATE_BATCH = 0 is the one-load-at-a-time form of the gated rows, FFC_RP_HOIST = 0 the multi-pass rows with the access-width switch
-inside every load, FFC_KF_LATE = 1 the prepared backward variant).  One simulator build with every switch flipped, compared with the
+inside every load).  One simulator build with every switch flipped, compared with the
 default simulator on forward, backward and the spectrum-saving pair of single-tile, fused and multi-pass sizes, gated and ragged."""
 import ctypes, hashlib, os, subprocess, sys
 import numpy as np
@@ -13,7 +13,7 @@ PKG = os.path.join(os.path.dirname(HERE), "flash-fft-conv_amd")
 # FFC_PK_GATE = 0: fp16 gate multiplies through fp32 (the packed fp16 multiply rounds the exact product once: the same bits)
 # round 6: FFC_IP_MERGE = 0 is the fft-2048 forward with one row load / one read-modify-write of the output per PASS (the default keeps the pair's rows
 # and the passes' sum in registers: one load, one store)
-ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_KF_LATE=1", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0", "-DFFC_PK_GATE=0", "-DFFC_IP_MERGE=0"]
+ALT_FLAGS = ["-DFFC_GATE_BATCH=0", "-DFFC_RP_HOIST=0", "-DFFC_OUTER_QUAD=0", "-DFFC_RP_FASTK=0", "-DFFC_PK_GATE=0", "-DFFC_IP_MERGE=0"]
 
 
 def _alt_sim():
