@@ -117,6 +117,8 @@ def compact(out):
                                                      for r in out["configs"] if r["row"].split(" ")[0] in fr}
     if out.get("readme_table"):
         c["readme_x_h100"] = {str(r["fft"]): r["speedup_vs_h100_published"] for r in out["readme_table"]}
+        if all("speedup_vs_h100_timer" in r for r in out["readme_table"]):      # the same rows timed with the reference's tool (host clock)
+            c["readme_x_h100_timer"] = {str(r["fft"]): r["speedup_vs_h100_timer"] for r in out["readme_table"]}
         if all("bwd_ms_scaled" in r for r in out["readme_table"]):
             c["readme_gated_fwd_bwd_ms"] = {str(r["fft"]): [r["fwd_ms_scaled_to_B64_H768"], r["bwd_ms_scaled"]] for r in out["readme_table"]}
     if out.get("strong_rows"):      # N > 1: the fixed-problem rows of the metric's grid, [fwd+bwd ms, heads per rank] (max over ranks)

@@ -230,6 +230,11 @@ def readme_rows(sizes=None):
         g = [torch.randn(B, H, N, device="cuda").to(torch.float16).requires_grad_(True) for _ in range(2)]
         mod = FlashFFTConv(N, dtype=torch.float16).cuda()
         (t, tmin) = ev_time(lambda: mod(u, k, *g), set_iters(N))
+        # the reference's own tool and call (benchmarks/benchmark.py:8-24: torch.utils.benchmark.Timer(...).timeit(repeats), mean): host time
+        # around `repeats` calls with one synchronisation at the end, so it includes whatever the host adds when the launches are short
+        import torch.utils.benchmark as tbench
+        t_timer = tbench.Timer(stmt="mod(u, k, *g)", globals={"mod": mod, "u": u, "k": k, "g": g},
+                               num_threads=torch.get_num_threads()).timeit(set_iters(N)).mean * 1e3
         with torch.no_grad():       # the same forward without what the training forward stores for the backward pass
             mod.eval()
             (ti, _) = ev_time(lambda: mod(u, k, *g), set_iters(N))
@@ -253,8 +258,9 @@ def readme_rows(sizes=None):
         del dout
         yield {"row": f"README table N={N}", "peak_mem_bytes": pm, "fft": N, "L": N, "dtype": "float16", "gated": True, "B_run": B, "H_run": H,
                "fwd_ms_scaled_to_B64_H768": round(t * adj, 3), "fwd_ms_min_scaled": round(tmin * adj, 3),
-               "fwd_no_grad_ms_scaled": round(ti * adj, 3), "bwd_ms_scaled": round(tb * adj, 3),
-               "h100_ms_published": H100_GATED_FWD_MS[N], "speedup_vs_h100_published": round(H100_GATED_FWD_MS[N] / (t * adj), 2)}
+               "fwd_ms_timer_scaled": round(t_timer * adj, 3), "fwd_no_grad_ms_scaled": round(ti * adj, 3), "bwd_ms_scaled": round(tb * adj, 3),
+               "h100_ms_published": H100_GATED_FWD_MS[N], "speedup_vs_h100_published": round(H100_GATED_FWD_MS[N] / (t * adj), 2),
+               "speedup_vs_h100_timer": round(H100_GATED_FWD_MS[N] / (t_timer * adj), 2)}
         del u, k, g
         torch.cuda.empty_cache()
 

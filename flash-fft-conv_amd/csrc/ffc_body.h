@@ -1786,7 +1786,9 @@ struct Body {
                                 uint8_t* zs = nullptr) {
     A16 re, im;
     tile_fwd<true, IP>(tau, R, un, re, im, ip);
-    if constexpr (SZ) z_store(zs, 0, re, im, FFC_Z_STREAM);
+    if constexpr (SZ) {      // (single-tile sizes: zs may be null -- the gated forward that keeps only the output before the postgate, ConvArgs::yraw)
+      if (GEO::OUTER || zs) z_store(zs, 0, re, im, FFC_Z_STREAM);
+    }
     // (x) k_f
 #pragma unroll
     for (int rq = 0; rq < 4; rq++) {
@@ -2504,7 +2506,7 @@ struct Body {
                 }
               }
               B::lds_fence();
-              inner_tile<true, SZ>(a, 0, R, un, kf, &ip, SZ ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
+              inner_tile<true, SZ>(a, 0, R, un, kf, &ip, (SZ && a.zsave) ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
               B::lds_fence();
 #pragma unroll
               for (int ii = 0; ii < NCH; ii++) {
@@ -2554,7 +2556,7 @@ struct Body {
             load_kf(a, h * a.R + k0, 0, kf);
             rows_in_rp<NCH>(a, h, q, un, ps);
             B::lds_fence();
-            inner_tile<true, SZ>(a, 0, R, un, kf, &ip, SZ ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
+            inner_tile<true, SZ>(a, 0, R, un, kf, &ip, (SZ && a.zsave) ? z_slot_small(a.zsave, h, a.npair, q, a.R, k0) : nullptr);
             B::lds_fence();
             if constexpr (SZ) {
               if (a.yraw) {      // output before the postgate multiply (dpostgate = dout * this)
@@ -2578,7 +2580,7 @@ struct Body {
           load_kf(a, h, 0, kf);
           rows_in(a, h, q, un);
           B::lds_fence();
-          inner_tile<false, SZ>(a, 0, R, un, kf, nullptr, SZ ? z_slot_small(a.zsave, h, a.npair, q, 1, 0) : nullptr);
+          inner_tile<false, SZ>(a, 0, R, un, kf, nullptr, (SZ && a.zsave) ? z_slot_small(a.zsave, h, a.npair, q, 1, 0) : nullptr);
           B::lds_fence();
           if constexpr (SZ) {
             if (a.yraw) {

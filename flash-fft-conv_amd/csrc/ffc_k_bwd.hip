@@ -66,7 +66,9 @@ static int conv_bwd_impl(const ffc_plan* p, const void* dout, const void* u, con
   // `u` is read by the recomputing kernels, as the gate of dpregate and by the forward run that makes dpostgate without y_raw; on saved
   // spectra without gates nothing reads it and a null pointer says so (the HBM-level sizes' inner call, flashfftconv/conv.py _big_backward)
   if (!u && (!zin || pregate || postgate || dpre || (dpost && !yraw))) return ffc_fail("null u: only with saved spectra and no gates");
-  if (yraw && (!zin || !dpost)) return ffc_fail("y_raw needs the saved spectra and a dpost output");
+  if (yraw && !dpost) return ffc_fail("y_raw needs a dpost output");
+  // (single-tile sizes, fft <= 2048: y_raw also without the spectra -- the kernel transforms u * pregate again, rows it loads anyway)
+  if (yraw && !zin && p->hp.N1 > 1) return ffc_fail("y_raw without the saved spectra: single-tile sizes (fft <= 2048) only");
   if (zin && (ffc_spectrum_bytes(p, B, H) == 0 || ((uintptr_t)zin & 15))) return ffc_fail("spectrum buffer: unsupported plan or misaligned");
   if (B <= 0 || H <= 0) return ffc_fail("empty batch/heads");
   if (L <= 0 || L > p->hp.N) return ffc_fail("L must be in (0, fft_size]");
@@ -170,7 +172,7 @@ extern "C" int ffc_conv_bwd_zy(const ffc_plan* p, const void* dout, const void* 
                                const void* postgate, void* du, void* dpre, void* dpost, void* ws, const void* zin, const void* y_raw,
                                int64_t B, int64_t H, int64_t L, int64_t sb_dout, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                                int64_t sb_du, int64_t sb_dpre, int64_t sb_dpost, void* stream) {
-  if (!zin || !y_raw || !dpost) return ffc_fail("null spectrum / y_raw / dpost buffer");
+  if ((!zin && !(p && p->hp.N1 <= 1)) || !y_raw || !dpost) return ffc_fail("null spectrum / y_raw / dpost buffer (y_raw alone: single-tile sizes, fft <= 2048)");
   return conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, sb_dout, sb_u, sb_pre, sb_post, sb_du,
                        sb_dpre, sb_dpost, stream, y_raw);
 }
@@ -189,7 +191,7 @@ extern "C" int ffc_conv_bwd_k(const ffc_plan* p, const void* dout, const void* u
                               int64_t B, int64_t H, int64_t L, void* stream) {
   if (!dk) return ffc_fail("null dk");
   bool dk_done = false;
-  const void* yr = (zin && y_raw && dpost) ? y_raw : nullptr;
+  const void* yr = ((zin || p->hp.N1 <= 1) && y_raw && dpost) ? y_raw : nullptr;
   int rc = conv_bwd_impl(p, dout, u, kf, pregate, postgate, du, dpre, dpost, ws, zin, B, H, L, 0, 0, 0, 0, 0, 0, 0, stream, yr, dk, Lk,
                          &dk_done);
   if (rc || dk_done) return rc;

@@ -101,7 +101,7 @@ struct ConvLaunch {
       } else if constexpr (GEO::N == 1024) {
         constexpr int lds = GEO::LDS_BYTES + 2 * BD::IPASS_BYTES;
         const int cap = (a.persist > 0 && a.persist < (1 << 29)) ? 2 * a.persist : (1 << 30);      // FFC_PERSIST=0: uncapped
-        if (a.zsave) {
+        if (a.zsave || a.yraw) {
           int rc = ffc_set_lds(conv_rp_kernel<GEO, DT, false, true>, lds);
           if (rc) return rc;
           hipLaunchKernelGGL((conv_rp_kernel<GEO, DT, false, true>), dim3(grid > cap ? cap : grid), dim3(GEO::WGW * 64), GEO::LDS_BYTES + a.R * BD::IPASS_BYTES, st, a);
@@ -135,7 +135,7 @@ struct ConvLaunch {
         return ffc_fail("frequency-sparse kernel: fft 16384 / 32768 only");
       }
     }
-    if (a.zsave) {
+    if (a.zsave || (!GEO::OUTER && a.yraw)) {
       if constexpr (GEO::OUTER) {
         if ((GEO::N1 / 2) * GEO::Mi >= a.L) {
           int rc = ffc_set_lds(conv_kernel<GEO, DT, true, true>, GEO::LDS_BYTES);
@@ -203,7 +203,9 @@ static int conv_fwd_impl(const ffc_plan* p, const void* u, const void* kf, const
   a.B = (int)B; a.H = (int)H; a.L = (int)L; a.npair = (int)((B + 1) / 2);
   a.sbu = sb_u; a.sbg = sb_pre; a.sbp = sb_post; a.sby = sb_y;
   a.conj_kf = conj_kf;
-  a.zsave = zsave; a.yraw = zsave ? yraw : nullptr;
+  // y_raw without the spectra: the single-tile sizes (fft <= 2048) only -- their backward transforms u * pregate again from rows it
+  // loads anyway (dpregate, du) and takes dpostgate = dout * y_raw from its dout row load (round 6)
+  a.zsave = zsave; a.yraw = (zsave || p->hp.N1 <= 1) ? yraw : nullptr;
   a.sparse = sparse;
   if (sparse && (sparse < 0 || sparse > 4 || zsave || p->hp.R > 1 || p->hp.N2 != 32 || p->hp.N3 != 32 || p->hp.N1 <= 1))
     return ffc_fail("frequency-sparse forward: fft 16384 / 32768, 1 <= rows <= 4, no spectrum buffer");
@@ -245,7 +247,7 @@ extern "C" int ffc_conv_fwd_strided(const ffc_plan* p, const void* u, const void
 extern "C" int ffc_conv_fwd_z(const ffc_plan* p, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
                               void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,
                               int64_t sb_y, void* stream) {
-  if (!zsave) return ffc_fail("null spectrum buffer");
+  if (!zsave && !(y_raw && p && p->hp.N1 <= 1)) return ffc_fail("null spectrum buffer (y_raw alone: single-tile sizes, fft <= 2048)");
   if (y_raw && ((uintptr_t)y_raw & 15)) return ffc_fail("y_raw must be 16-byte aligned");
   return conv_fwd_impl(p, u, kf, pregate, postgate, y, zsave, y_raw, 0, B, H, L, 0, sb_u, sb_pre, sb_post, sb_y, stream);
 }
@@ -324,7 +326,7 @@ extern "C" int ffc_conv_fwd_k(const ffc_plan* p, const float* k, int64_t Lk, voi
     if (rc) return rc;
   }
   bool done = false;
-  int rc = conv_fwd_impl(p, u, kf_out, pregate, postgate, y, zsave, zsave ? y_raw : nullptr, 0, B, H, L, 0, 0, 0, 0, 0, stream,
+  int rc = conv_fwd_impl(p, u, kf_out, pregate, postgate, y, zsave, y_raw, 0, B, H, L, 0, 0, 0, 0, 0, stream,
                          fuse ? k : nullptr, Lk, &done);
   if (rc) return rc;
   if (fuse && !done) return ffc_fail("internal: the convolution launch did not take the k -> k_f step");

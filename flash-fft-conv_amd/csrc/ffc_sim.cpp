@@ -357,7 +357,8 @@ static void sim_conv_t(const ConvArgs& a) {
           run_wg(GEO::WGW, GEO::LDS_BYTES + a.R * Body<SimB, GEO, DT>::IPASS_BYTES, [&]() {
             Body<SimB, GEO, DT>::setup_tables(a.tab, a.t);
             Body<SimB, GEO, DT>::setup_tables_ipass(a.tab, a.t, a.R);
-            Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
+            if (a.zsave || a.yraw) Body<SimB, GEO, DT>::template conv_job<false, true, true>(a, h, c);      // conv_rp_kernel<.., SZ>
+            else Body<SimB, GEO, DT>::template conv_job<false, true>(a, h, c);
           });
           continue;
         }
@@ -387,6 +388,9 @@ static void sim_conv_t(const ConvArgs& a) {
             return;
           }
           if ((GEO::N1 / 2) * GEO::Mi >= a.L) { Body<SimB, GEO, DT>::template conv<true>(a, h, c); return; }
+        } else {
+          // single-tile sizes: the training forward that keeps the spectra and / or the output before the postgate (conv_kernel<.., SZ>)
+          if (a.zsave || a.yraw) { Body<SimB, GEO, DT>::template conv<false, true>(a, h, c); return; }
         }
         Body<SimB, GEO, DT>::conv(a, h, c);
       });
@@ -568,6 +572,7 @@ int ffcsim_conv_fwd(int N, int dtype, const void* u, const void* kf, const void*
   a.R = p.R;
   a.sparse = g_sparse_rows;
   if (p.N1 > 1 && p.R == 1) { a.zsave = g_z; a.yraw = g_z ? g_yraw : nullptr; }
+  if (p.N1 <= 1) { a.zsave = g_z; a.yraw = g_yraw; }      // single-tile sizes: either one alone too (conv_fwd_impl)
   if (g_kfuse_x && N >= 8192 && N <= 32768 && !a.sparse) {
     a.kfuse_x = g_kfuse_x; a.kfuse_scale = g_kfuse_xscale; a.kfuse_Lk = N; a.kfuse_fast = 1;
   }
@@ -717,8 +722,9 @@ int ffcsim_conv_bwd(int N, int dtype, const void* dout, const void* u, const voi
   a.ppc = ipc * per_iter; a.nchunk = (a.npair + a.ppc - 1) / a.ppc;
   a.fast = (L % 8 == 0) && !g_force_slow;
   a.R = p.R;
-  d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = p.N1 > 1 ? dpost : nullptr;
+  d.dout = dout; d.ws = ws; d.du = du; d.dpre = dpre; d.dpost = (p.N1 > 1 || g_yraw) ? dpost : nullptr;
   if (p.N1 > 1 && p.R == 1 && g_z) { d.zin = g_z; d.yraw = g_yraw; a.flags = g_flags; a.stream = 1; }
+  if (p.N1 <= 1) { d.zin = g_z; d.yraw = dpost ? g_yraw : nullptr; }      // (conv_bwd_impl: y_raw with or without the spectra)
   HostPlan pbf;
   if (g_dk_pair && a.nchunk == 1 && N >= 8192 && N <= 32768) {
     d.dk_pair = g_dk_pair; d.Lk = N; d.dk_scale = g_dk_pair_scale; d.dk_fast = 1;

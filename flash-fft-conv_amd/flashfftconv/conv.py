@@ -170,6 +170,10 @@ def _conv_sparse(plan, u, kf, pregate, postgate, conj, rows):
 # FFC_SPECTRUM_FRACTION (default 1/8) of the memory that is free at that moment (device free + the caching allocator's unused
 # reserve): layer after layer the rule limits itself, the total can never exceed the free memory at the first layer and the
 # last 7/8 of whatever is left always stay available to the rest of the model.  module.save_spectrum = "always" skips the test.
+# gated forward at the single-tile sizes: largest fft size that keeps y_raw WITHOUT the spectra (the C-ABI takes it up to 2048).  A MEMORY option, off
+# by default (0: spectra and y_raw): at fft 1024 B64 H768 the kept bytes drop by a third (318 -> 217 MB peak), the forward gains 9 %, the backward --
+# which then reads u and pregate twice, for the transform and for the gate gradients -- loses 10 %; fwd + bwd +2 % (profiles/r06_ab_y_only.txt)
+_Y_ONLY_MAX = int(_os.environ.get("FFC_Y_ONLY_MAX", "0"))
 _SPEC_FRACTION = float(_os.environ.get("FFC_SPECTRUM_FRACTION", "0.125"))
 _SPEC_SMALL = 8 << 20          # below this a request is not worth a hipMemGetInfo call (the OOM fallback still covers it)
 _free_cache = {}
@@ -614,8 +618,12 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if rows:
                 out = _conv_sparse(plan, u, kf, pregate, postgate, False, rows)
             elif mod.training and mod.save_spectrum and _recording() and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
-                z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated, mod.save_spectrum)
-                if z is not None and ctx.gated:
+                # Gated single-tile sizes, opt-in (fft <= _Y_ONLY_MAX, round 6): keep ONLY the output before the postgate; the backward
+                # transforms u * pregate again (see _Y_ONLY_MAX: a third less kept memory at the same fwd + bwd time +- 3 %).
+                y_only = ctx.gated and plan.seqlen <= _Y_ONLY_MAX
+                if not y_only:
+                    z = _spectrum_buffer(plan, u.shape[0], u.shape[1], u.device, ctx.gated, mod.save_spectrum)
+                if (z is not None or y_only) and ctx.gated:
                     try:
                         yraw = torch.empty_like(u)
                     except torch.cuda.OutOfMemoryError:
@@ -631,14 +639,16 @@ class _FlashFFTConvFn(torch.autograd.Function):
                 if mod.cache_kf and not k.requires_grad:
                     mod._kf_cache = (_kf_key(k), kf)
             elif not rows:
-                out = _conv(plan, u, kf, pregate, postgate, False) if z is None else _conv_save(plan, u, kf, pregate, postgate, z, yraw)
+                out = (_conv(plan, u, kf, pregate, postgate, False) if z is None and yraw is None
+                       else _conv_save(plan, u, kf, pregate, postgate, z, yraw))
         if mod.training:  # reference saves for backward only in training mode (conv.py:587-588)
             # (z, yraw: saved tensors, released with the graph and kept by retain_graph like the others)
             if ctx.big:
                 extra = () if kept is None else tuple(t for t in kept if t is not None)
                 ctx.kept_layout = None if kept is None else tuple(t is not None for t in kept)
             else:
-                extra = () if z is None else ((z, yraw) if ctx.gated else (z,))
+                extra = tuple(t for t in (z, yraw) if t is not None)      # (z, yraw) | (z,) | (yraw,): gated single-tile sizes keep y_raw alone
+                ctx.kept_z = z is not None
             ctx.save_for_backward(*(((u, kf, pregate, postgate) if ctx.gated else (u, kf)) + extra))
         return out
 
@@ -656,7 +666,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
         if ctx.gated:
             u, kf, pregate, postgate = ctx.saved_tensors[:4]
             if len(ctx.saved_tensors) > 4:
-                z, yraw = ctx.saved_tensors[4:6]
+                z, yraw = ctx.saved_tensors[4:6] if getattr(ctx, "kept_z", True) else (None, ctx.saved_tensors[4])
         else:
             (u, kf), pregate, postgate = ctx.saved_tensors[:2], None, None
             z = ctx.saved_tensors[2] if len(ctx.saved_tensors) > 2 else None
@@ -685,7 +695,7 @@ class _FlashFFTConvFn(torch.autograd.Function):
             if dk.dtype != ctx.k_dtype:
                 dk = dk.to(ctx.k_dtype)
             return (du, dk, None, dpre, dpost) if ctx.gated else (du, dk, None, None, None)
-        if z is not None and ctx.gated:
+        if (z is not None or yraw is not None) and ctx.gated:
             # dpostgate = dout * y_raw out of the kernel's dout row load (round 3: a torch elementwise kernel, 3 x |u| bytes more)
             _lib.check(lib.ffc_conv_bwd_zy(plan.handle, _lib.ptr(dout), _lib.ptr(u), _lib.ptr(kf), _lib.ptr(pregate),
                                            _lib.ptr(postgate), _lib.ptr(du), _lib.ptr(dpre), _lib.ptr(dpost), _lib.ptr(ws), _lib.ptr(z),

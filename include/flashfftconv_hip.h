@@ -98,7 +98,10 @@ int ffc_conv_bwd_gated_strided(const ffc_plan* plan, const void* dout, const voi
  * (fft <= 2048) one 4 KB slot per tile of G pairs and pass.  There the forward output of ffc_conv_fwd_z agrees with
  * ffc_conv_fwd to last-bit steps of the dtype (two instantiations of the same arithmetic), for fft >= 4096 bit for bit.
  * y_raw (nullable; contiguous (B,H,L) dtype): the forward output before the postgate multiply.  The gated backward's
- * dpostgate is dout * y_raw -- with it the caller passes dpost = NULL to ffc_conv_bwd_z and that kernel runs no third transform. */
+ * dpostgate is dout * y_raw -- with it the caller passes dpost = NULL to ffc_conv_bwd_z and that kernel runs no third transform.
+ * Single-tile sizes (fft <= 2048), round 6: y_raw may be kept WITHOUT the spectra -- ffc_conv_fwd_z / ffc_conv_fwd_k with zsave = NULL and
+ * y_raw given, ffc_conv_bwd_zy / ffc_conv_bwd_k with zin = NULL and y_raw given: the backward transforms u * pregate again (bit for bit the
+ * recomputing kernel's du, dpregate and dk_f sums) and takes dpostgate from y_raw.  A third less kept memory; the module's FFC_Y_ONLY_MAX. */
 int64_t ffc_spectrum_bytes(const ffc_plan* plan, int64_t B, int64_t H);
 int ffc_conv_fwd_z(const ffc_plan* plan, const void* u, const void* kf, const void* pregate, const void* postgate, void* y,
                    void* zsave, void* y_raw, int64_t B, int64_t H, int64_t L, int64_t sb_u, int64_t sb_pre, int64_t sb_post,

@@ -227,14 +227,17 @@ def sim_bwd(N, dtype, dout_bits, u_bits, kf_bits, Lk, pre=None, post=None, nchun
     return du, dpre, dk
 
 
-def sim_fwd_bwd_z(N, dtype, u_bits, dout_bits, kf_bits, pre=None, post=None, nchunk=1, flags=0):
+def sim_fwd_bwd_z(N, dtype, u_bits, dout_bits, kf_bits, pre=None, post=None, nchunk=1, flags=0, keep="zy"):
     """the spectrum-saving pair on the simulator (ffc_conv_fwd_z -> ffc_conv_bwd_z / _zy): forward output, du, dpre, dpost bits and
-    the fp32 dk_f slabs.  flags: ConvArgs::flags of the backward (8 = no LDS-DMA input rows)."""
+    the fp32 dk_f slabs.  flags: ConvArgs::flags of the backward (8 = no LDS-DMA input rows).  keep = "y": the gated single-tile form that
+    keeps the output before the postgate WITHOUT the spectra (fft <= 2048; the backward transforms u * pregate again)."""
     B, H, L = u_bits.shape
     nt, _, _, _ = plan_info(N, dtype)
     upw = lib().ffcsim_upw(N)
-    z = np.zeros(((B + 1) // 2) * H * N * 2, np.uint16)
+    # (single-tile sizes: one 4 KB slot per tile of G pairs and pass, ffc_spectrum_bytes -- a slot per pair is enough room)
+    z = np.zeros(((B + 1) // 2) * H * max(N, 1024) * 2, np.uint16) if "z" in keep else None
     yraw = np.zeros_like(u_bits) if pre is not None else None
+    assert z is not None or (yraw is not None and N <= 2048)
     y = np.zeros_like(u_bits)
     lib().ffcsim_set_z(p(z), p(yraw), 0)
     try:

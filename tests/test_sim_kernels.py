@@ -375,6 +375,40 @@ def test_saved_spectrum_backward_and_dma_rows(N, L, B, H, nch, gated, dt):
         assert rel(S.from_bits(dpost, dt), r[3]) < TOL[dt]
 
 
+# ---------------------------------------------------------------- single-tile sizes (fft <= 2048): the training forward that keeps the pair's
+# spectrum and / or the output before the postgate (conv_kernel<.., SZ>, conv_rp_kernel<.., SZ>) and the backward on them.  Round 6: the gated
+# form keeps the output ALONE (keep = "y": the backward transforms u * pregate again from rows it loads anyway) -- every result bit for bit
+# what the recomputing kernels and the both-kept form give, dpostgate = dout * y_raw against the oracle
+@pytest.mark.parametrize("N,L,B,H,gated", [(1024, 1024, 4, 2, True), (1024, 500, 3, 2, True), (256, 256, 9, 1, True), (256, 100, 5, 2, True),
+                                           (2048, 1024, 4, 1, True), (2048, 2048, 3, 1, True), (2048, 1500, 2, 1, True), (1024, 1024, 4, 1, False),
+                                           (2048, 1024, 3, 1, False)])
+@pytest.mark.parametrize("dt", [0, 1])
+def test_single_tile_kept_output_and_spectrum(N, L, B, H, gated, dt):
+    rng = np.random.default_rng(N + L + B + dt)
+    u, d, g1, g2 = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.1).astype(np.float32)
+    kf = S.sim_kernel_fft(N, dt, k)
+    pre = S.to_bits(g1, dt) if gated else None
+    post = S.to_bits(g2, dt) if gated else None
+    ub, db = S.to_bits(u, dt), S.to_bits(d, dt)
+    y0 = S.sim_conv_fwd(N, dt, ub, kf, pre, post)
+    du0, dpre0, dk0 = S.sim_bwd(N, dt, db, ub, kf, L, pre, post, 1)
+    nt, _, _, _ = S.plan_info(N, dt)
+    r = O.ref_grads(q(u, dt), k, q(d, dt), N, q(g1, dt), q(g2, dt)) if gated else O.ref_grads(q(u, dt), k, q(d, dt), N)
+    for keep in (("zy", "y") if gated else ("zy",)):
+        y, du, dpre, dpost, ws = S.sim_fwd_bwd_z(N, dt, ub, db, kf, pre, post, 1, keep=keep)
+        assert np.array_equal(y, y0), keep
+        assert np.array_equal(du, du0), keep
+        dk = np.full((H, L), np.nan, np.float32)
+        assert S.lib().ffcsim_kernel_ifft_grad(N, dt, S.p(ws), ws.size // (H * nt * 2048), H, L, S.p(dk)) == 0
+        if keep == "y":
+            assert np.array_equal(dk, dk0), "the recomputed spectrum is the recomputing kernel's"
+        assert rel(dk, dk0.astype(np.float64)) < 3e-3 and rel(dk, r[1]) < 1.5 * TOL[0]
+        if gated:
+            assert np.array_equal(dpre, dpre0), keep
+            assert rel(S.from_bits(dpost, dt), r[3]) < TOL[dt], keep
+
+
 # ---------------------------------------------------------------- HBM-level outer pass: persistent double-buffered form (BigBody::run_pipe:
 # next block's rows by LDS-DMA into the idle exchange buffer) against the one-block-per-workgroup form -- same arithmetic, bit for bit
 @pytest.mark.parametrize("n0,mi,B,H,L,gated", [(32, 1024, 3, 2, 32768, False),     # 3 "workgroups" x 4 blocks, odd batch (missing Im row)

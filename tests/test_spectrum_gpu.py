@@ -57,6 +57,18 @@ def _call_pair(N, B, H, L, dtype, gated):
         assert torch.equal(o3[0], o1[0]) and torch.equal(o3[1], o1[1]), "du / dpregate changed by the fused dpostgate"
         nsl = lib.ffc_dkf_slab_count(plan.handle, B, H) * H * plan.kf_elems * 2 * 4
         assert torch.equal(ws3[:nsl], ws1[:nsl]), "dk_f sums changed by the fused dpostgate"
+        if N <= 2048:
+            # round 6, single-tile sizes: y_raw kept WITHOUT the spectra (the module's gated form at fft <= 1024) -- the backward transforms
+            # u * pregate again, exactly as the recomputing kernel does, and takes dpostgate from y_raw
+            y4, yraw4 = torch.full_like(u, 19.0), torch.full_like(u, 23.0)
+            _lib.check(lib.ffc_conv_fwd_z(plan.handle, P(u), P(kf), P(pre), P(post), P(y4), None, P(yraw4), B, H, L, 0, 0, 0, 0, sp()), "fwd_z (y_raw alone)")
+            assert torch.equal(y4, y1) and torch.equal(yraw4, yraw), "forward output changed by leaving the spectrum store out"
+            o4 = [torch.full_like(u, 29.0) for _ in range(3)]; ws4 = torch.empty_like(ws0)
+            _lib.check(lib.ffc_conv_bwd_zy(plan.handle, P(dout), P(u), P(kf), P(pre), P(post), P(o4[0]), P(o4[1]), P(o4[2]), P(ws4), None, P(yraw4),
+                                           B, H, L, 0, 0, 0, 0, 0, 0, 0, sp()), "bwd_zy (y_raw alone)")
+            assert torch.equal(o4[0], o0[0]) and torch.equal(o4[1], o0[1]), "du / dpregate (y_raw alone) != the recomputing kernel's"
+            assert torch.equal(o4[2], o1[2]), "dpostgate (y_raw alone) != dout * y_raw"
+            assert torch.equal(ws4[:nsl], ws0[:nsl]), "dk_f sums (y_raw alone) != the recomputing kernel's"
     dk0 = torch.empty(H, L, device="cuda"); dk1 = torch.empty(H, L, device="cuda")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws0), B, H, L, P(dk0), sp()), "dk")
     _lib.check(lib.ffc_kernel_ifft_grad(plan.handle, P(ws1), B, H, L, P(dk1), sp()), "dk")
@@ -105,6 +117,7 @@ def test_module_gradients_with_saved_spectrum(N, gated, dtype):
     gates = [torch.randn_like(u) * 0.5 for _ in range(2)] if gated else []
     dout = torch.randn_like(u) * 0.02
     grads = {}
+    from flashfftconv import conv as C
     for save in (True, False):
         conv = FlashFFTConv(N, dtype=dtype).cuda()
         conv.save_spectrum = save
@@ -114,6 +127,20 @@ def test_module_gradients_with_saved_spectrum(N, gated, dtype):
         g2 = torch.autograd.grad(out, leaves, dout)
         assert all(torch.equal(a, b) for a, b in zip(g, g2)), "second backward through a retained graph differs"
         grads[save] = (out.detach(), g)
+    y_only_max = C._Y_ONLY_MAX
+    if gated and N <= 2048:
+        # the gated single-tile sizes keeping y_raw WITHOUT the spectra (round 6, opt-in: FFC_Y_ONLY_MAX) against the default (both kept)
+        try:
+            C._Y_ONLY_MAX = 0 if N <= y_only_max else 2048
+            conv = FlashFFTConv(N, dtype=dtype).cuda()
+            leaves = [u.clone().requires_grad_(True), k.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in gates]
+            out = conv(*leaves)
+            grads["both"] = (out.detach(), torch.autograd.grad(out, leaves, dout))
+        finally:
+            C._Y_ONLY_MAX = y_only_max
+        # same forward instantiation, du / dpregate from the same arithmetic, dpostgate = dout * the same y_raw: bit for bit
+        assert torch.equal(grads["both"][0], grads[True][0])
+        assert all(torch.equal(grads["both"][1][i], grads[True][1][i]) for i in (0, 2, 3))
     if N >= 4096:
         assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1][0], grads[False][1][0])
     else:       # single-tile kernels: equal to last-bit steps (see test_saved_spectrum_equals_recompute)
@@ -123,7 +150,7 @@ def test_module_gradients_with_saved_spectrum(N, gated, dtype):
     (ref,) = stable(fwd, "forward")
     gref = stable(lambda: torch.autograd.grad(ref, lc, dout.clone(), retain_graph=True), "backward")
     tol = REL[dtype] * (1.5 if gated else 1.0)
-    for save in (True, False):
+    for save in grads:
         out, g = grads[save]
         assert rel(out, ref) < tol and rel(g[0], gref[0]) < tol
         assert rel(g[1], gref[1]) < max(tol, 1e-2 * (1.5 if gated else 1.0)), f"dk rel-L2 {rel(g[1], gref[1]):.3e}"
@@ -141,6 +168,17 @@ def test_spectrum_buffer_is_refused_when_misaligned_or_missing():
     assert rc != 0 and b"spectrum" in lib.ffc_last_error()
     rc = lib.ffc_conv_fwd_z(plan.handle, _lib.ptr(u), _lib.ptr(kf), None, None, _lib.ptr(u), None, None, 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
     assert rc != 0
+    # y_raw without the spectra is a single-tile form (fft <= 2048): refused by the fused sizes in either direction
+    plan4 = FlashFFTConv(4096, dtype=torch.bfloat16).cuda()._get_plan(torch.device("cuda", 0))
+    kf4 = torch.zeros(8, plan4.kf_elems, 2, device="cuda", dtype=torch.bfloat16)
+    g, yr, ws = torch.ones_like(u), torch.zeros_like(u), torch.zeros(lib.ffc_dkf_workspace_bytes(plan4.handle, 2, 8), dtype=torch.uint8, device="cuda")
+    outs = [torch.zeros_like(u) for _ in range(4)]
+    P = _lib.ptr
+    rc = lib.ffc_conv_fwd_z(plan4.handle, P(u), P(kf4), P(g), P(g), P(outs[0]), None, P(yr), 2, 8, 512, 0, 0, 0, 0, _lib.stream_ptr())
+    assert rc != 0 and b"single-tile" in lib.ffc_last_error()
+    rc = lib.ffc_conv_bwd_zy(plan4.handle, P(u), P(u), P(kf4), P(g), P(g), P(outs[1]), P(outs[2]), P(outs[3]), P(ws), None, P(yr), 2, 8, 512,
+                             0, 0, 0, 0, 0, 0, 0, _lib.stream_ptr())
+    assert rc != 0 and b"single-tile" in lib.ffc_last_error()
 
 
 @pytest.mark.gpu
