@@ -138,6 +138,23 @@ static int launch_big_all(const BigArgs& a, hipStream_t st) {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : ffc_fail(std::string("big_all_kernel launch: ") + hipGetErrorString(e));
 }
+// the WIDE form (BigBody::run_wide, round 6): the long side holds up to R * 32 rows -- fft 4194304 = 128 x 32768 and 2097152 = 64 x 32768 in ONE level at
+// any length (the reference's 128- / 64-point butterflies take any length too: csrc/flashfftconv/butterfly/butterfly_padded_cuda_bf16.cu:302-487)
+template <int DT, bool FWD>
+__global__ __launch_bounds__(GeoBig<32>::WGW * 64, 2) void big_wide_kernel(BigArgs a) {
+  BigBody<DevB, 32, DT>::template run_wide<FWD>(a, blockIdx.x);
+}
+template <int DT, bool FWD>
+static int launch_big_wide(const BigArgs& a, hipStream_t st) {
+  int rc = ffc_set_lds(big_wide_kernel<DT, FWD>, GeoBig<32>::EBYTES);
+  if (rc) return rc;
+  const int cols = 128 * (GeoBig<32>::WGW / a.R);      // a workgroup's column block: WGW / R groups of 128, R waves (passes / row blocks) on each
+  const int64_t nwg = (int64_t)a.npair * a.Hin * (a.Mi / cols);
+  if (nwg <= 0 || nwg > 2147483647LL) return ffc_fail("outer pass: bad grid");
+  hipLaunchKernelGGL((big_wide_kernel<DT, FWD>), dim3((unsigned)nwg), dim3(GeoBig<32>::WGW * 64), GeoBig<32>::EBYTES, st, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : ffc_fail(std::string("big_wide_kernel launch: ") + hipGetErrorString(e));
+}
 // Same level as the R calls ffc_outer_pass_r(plan_r, c = 0 .. R-1, ...), in one launch.
 extern "C" int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, const void* in, void* out, const void* gate,
                                   int64_t Bv, int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream) {
@@ -145,7 +162,7 @@ extern "C" int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, co
   if (!p || !in || !out) return ffc_fail("null arg");
   if (p->hp.N1 != 32 || p->hp.R < 2 || p->hp.R > 4) return ffc_fail("outer pass (R passes): needs a multi-pass plan with a 32-point outer digit");
   if (Mi % GeoBig<32>::Mi) return ffc_fail("outer pass: Mi must be a multiple of the column block");
-  if (Llong <= 0 || Llong > 32 * Mi) return ffc_fail("outer pass (R passes): the long side must fit the first 32 rows (L <= N / R)");
+  if (Llong <= 0 || Llong > (int64_t)p->hp.R * 32 * Mi) return ffc_fail("outer pass (R passes): the long side is longer than the level (L > N)");
   BigArgs a{};
   a.in = in; a.out = out; a.gate = gate;
   dtype = decode_dtype(dtype, dir, &a);
@@ -160,6 +177,13 @@ extern "C" int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, co
   a.fast = (Llong % 8 == 0) && !(((uintptr_t)in | (uintptr_t)out | (uintptr_t)gate) & 15);
   a.R = p->hp.R; a.c = 0;
   hipStream_t st = (hipStream_t)stream;
+  if (Llong > 32 * Mi) {      // more than the first 32 long-side rows: the wide form
+    if (a.lf32 || a.half) return ffc_fail("outer pass (R passes), long side beyond the first 32 rows: 16-bit rows and all short-side rows only");
+    if (GeoBig<32>::WGW % a.R) return ffc_fail("outer pass (R passes), wide form: R must divide the workgroup's waves");
+    a.wide = 1;
+    if (bf) return dir ? launch_big_wide<DT_BF16, true>(a, st) : launch_big_wide<DT_BF16, false>(a, st);
+    return dir ? launch_big_wide<DT_F16, true>(a, st) : launch_big_wide<DT_F16, false>(a, st);
+  }
   if (bf) return dir ? launch_big_all<DT_BF16, true>(a, st) : launch_big_all<DT_BF16, false>(a, st);
   return dir ? launch_big_all<DT_F16, true>(a, st) : launch_big_all<DT_F16, false>(a, st);
 }

@@ -646,6 +646,19 @@ int ffcsim_big_outer_all(int R, int dtype, int fwd, const void* in, void* out, c
   a.Bp_valid = Bp_valid; a.npair = npair; a.Hin = Hin; a.Mi = Mi; a.Llong = Llong; a.scale = scale;
   a.fast = (Llong % 8 == 0) && !g_force_slow;
   if (Mi % GeoBig<32>::Mi) return -2;
+  if (Llong > R * 32 * Mi) return -5;
+  if (Llong > 32 * Mi) {      // the wide form (ffc_outer_pass_all: long side beyond the first 32 rows, BigBody::run_wide)
+    if (lf32 || half || GeoBig<32>::WGW % R) return -6;
+    a.wide = 1;
+    const int nw = npair * Hin * (Mi / (128 * (GeoBig<32>::WGW / R)));
+    for (int wg = 0; wg < nw; wg++) {
+#define FFC_BIGW(DD, FF) run_wg(GeoBig<32>::WGW, GeoBig<32>::LDS_BYTES, [&]() { BigBody<SimB, 32, DD>::template run_wide<FF>(a, wg); })
+      if (dtype == DT_BF16) { if (fwd) FFC_BIGW(DT_BF16, true); else FFC_BIGW(DT_BF16, false); }
+      else { if (fwd) FFC_BIGW(DT_F16, true); else FFC_BIGW(DT_F16, false); }
+#undef FFC_BIGW
+    }
+    return 0;
+  }
   const int nwg = npair * Hin * (Mi / GeoBig<32>::Mi);
   for (int wg = 0; wg < nwg; wg++) {
 #define FFC_BIGA(DD, FF) run_wg(GeoBig<32>::WGW, GeoBig<32>::LDS_BYTES, [&]() { BigBody<SimB, 32, DD>::template run_all<FF>(a, wg); })

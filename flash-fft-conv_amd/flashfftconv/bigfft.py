@@ -38,9 +38,22 @@ if _os.environ.get("FFC_BIG_1LEVEL", "0") == "1":
 ONE128 = {4194304: ((128,), 32768), 2097152: ((64,), 32768)} if _os.environ.get("FFC_BIG_ONE128", "1") != "0" else {}
 
 
+# Round 6: the same one-level factorisations at ANY length (the level's wide form, csrc/ffc_big.h BigBody::run_wide: up to R * 32 long-side rows, an R-point
+# butterfly of the row blocks in front of the pass matrices) -- fft 2M / 4M at L = N lose an HBM level resp. the 2-pass inner kernel and a quarter of the
+# step's peak memory (4M, B8 H16 gated: 8.05 -> 5.91 GB), but the level kernels pay for it in instructions: every wave of a column group repeats the
+# butterfly (forward) resp. the conj-twiddle product (inverse) of the rows the R waves share.  Measured (profiles/r06_ab_wide.txt): 2M +8 % / +14 %,
+# 4M +17 % / +33 % (fwd / bwd) against the round-5 routing -> OPT-IN (FFC_BIG_WIDE=1): a memory option; parity-green on the simulator and the GPU.
+WIDE = _os.environ.get("FFC_BIG_WIDE", "0") == "1"
+
+
+def is_wide(n0, mi, Llong):
+    """a level of factor 64 / 128 whose long side reaches beyond the first 32 rows"""
+    return n0 in (64, 128) and Llong > 32 * mi
+
+
 def choose(N, Lmax, ops=None):
     """(outer factors, fused inner size) for fft size N when no long-side row is longer than Lmax"""
-    if N in ONE128 and Lmax <= N // (ONE128[N][0][0] // 32) and getattr(ops, "HAS_128", False):
+    if N in ONE128 and getattr(ops, "HAS_128", False) and (Lmax <= N // (ONE128[N][0][0] // 32) or (WIDE and getattr(ops, "HAS_WIDE", False))):
         return ONE128[N]
     return BIG_FACTORS[N]
 
@@ -71,7 +84,8 @@ def rows_of(ops, n0):
 
 def half_ok(N, B, Lmax, ops=None):
     """the half-row form applies to a batch of ONE real row per head through a SINGLE level (the mirror relation is per level)"""
-    return B == 1 and len(choose(N, Lmax, ops)[0]) == 1
+    factors, M = choose(N, Lmax, ops)
+    return B == 1 and len(factors) == 1 and not is_wide(factors[0], N // factors[0], Lmax)      # (the wide form stores all rows)
 
 
 def level_scale(n0):

@@ -276,6 +276,7 @@ class _TorchOps:
         return torch.empty(Bp, Hx, n, dtype=dt, device=self.device)
 
     HAS_128 = True      # factor 128 as 4 passes of the 32-point kernel (bigfft.choose)
+    HAS_WIDE = True     # ... at any length (round 6: the level's wide form, ffc_outer_pass_all with Llong > 32 * Mi)
 
     # the levels read the fp32 filter / write the fp32 dk themselves (no cast kernels around them); FFC_BIG_LONG_F32=0: A/B switch
     LONG_F32 = _os.environ.get("FFC_BIG_LONG_F32", "1") != "0"
@@ -299,6 +300,18 @@ class _TorchOps:
         if n0 in (64, 128):
             R = n0 // 32
             pr = self._plan(32768 * R)      # the R-pass plan: its per-pass outer-digit tables are the matrices of the passes
+            if _big.is_wide(n0, mi, Llong):
+                # the wide form moves 16-bit rows: the fp32 filter is rounded in front of it (the product with its prescale, rounded once -- what the
+                # level's own fp32 load does) and the fp32 dk widened behind it (the level rounds its results to 16 bits before they leave LDS either way)
+                assert not self.half
+                if lf32 is not None and fwd:
+                    inp = torch.mul(inp, lf32).to(dt) if lf32 != 1.0 else inp.to(dt)
+                tmp = torch.empty(out.shape, dtype=dt, device=out.device) if (lf32 is not None and not fwd) else out
+                _lib.check(_lib.lib().ffc_outer_pass_all(pr.handle, _DT[dt], int(fwd), _lib.ptr(inp), _lib.ptr(tmp), _lib.ptr(gate), bv,
+                                                         npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_all (wide)")
+                if tmp is not out:
+                    out.copy_(tmp)
+                return
             if _ONE_LAUNCH_LEVEL:       # all R passes in one launch (long side read / written once)
                 _lib.check(_lib.lib().ffc_outer_pass_all(pr.handle, dcode, int(fwd), _lib.ptr(inp), _lib.ptr(out), _lib.ptr(gate), bv,
                                                          npair, Hin, mi, Llong, ctypes.c_float(scale), _lib.stream_ptr()), "ffc_outer_pass_all")
@@ -436,7 +449,10 @@ _BIG_HALF = _os.environ.get("FFC_BIG_HALF", "1") != "0"
 def _big_half(mod, B, Lmax, fac):
     """a batch of ONE row per head through a single HBM level: the half-row form (bigfft.rows_of) -- not for the frequency-sparse modules,
     whose masks are laid out over all inner rows"""
-    return _BIG_HALF and B == 1 and mod._kf_keep is None and len((fac or _big.BIG_FACTORS[mod.seqlen])[0]) == 1
+    factors, M = fac or _big.BIG_FACTORS[mod.seqlen]
+    if len(factors) != 1 or _big.is_wide(factors[0], mod.seqlen // factors[0], Lmax):      # (the level's wide form stores all rows)
+        return False
+    return _BIG_HALF and B == 1 and mod._kf_keep is None
 
 
 def _big_forward(mod, u, k, pregate, postgate, keep=False, kf=None, fac=None, half=False):

@@ -171,7 +171,11 @@ int ffc_outer_pass(const ffc_plan* plan16, const ffc_plan* plan32, int n0, int d
 int ffc_outer_pass_r(const ffc_plan* plan_r, int c, int dtype, int dir, const void* in, void* out, const void* gate, int64_t Bv,
                      int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream);
 /* The same level as the R calls ffc_outer_pass_r(plan_r, c = 0 .. R-1, ...) in ONE launch: the forward reads the long side once
- * (not R times), the inverse sums the passes in fp32 and writes the long side once (no read-modify-write between launches). */
+ * (not R times), the inverse sums the passes in fp32 and writes the long side once (no read-modify-write between launches).
+ * Round 6: Llong may exceed 32 * Mi (up to R * 32 * Mi, i.e. any length of the level: the reference's 128-point butterfly takes any length too,
+ * csrc/flashfftconv/butterfly/butterfly_padded_cuda_bf16.cu:302-487) -- the WIDE form: an R-point butterfly of the R long-side row blocks in front of
+ * the pass matrices.  16-bit long side only (no | 16, no | 32 in `dtype`).  Slower than two levels on MI355X (profiles/r06_ab_wide.txt) and a quarter
+ * less peak memory: the module takes it on request (FFC_BIG_WIDE=1). */
 int ffc_outer_pass_all(const ffc_plan* plan_r, int dtype, int dir, const void* in, void* out, const void* gate, int64_t Bv,
                        int64_t npair, int64_t Hin, int64_t Mi, int64_t Llong, float scale, void* stream);
 int ffc_kernel_fft_c(const ffc_plan* plan, const void* xpair, int64_t H, void* kf_out, float scale, void* stream);

@@ -123,6 +123,7 @@ class SimOps:
         return np.zeros((Bp, Hx, n), np.uint16)
 
     HAS_128 = True
+    HAS_WIDE = True
     one_launch = True
 
     LONG_F32 = True      # the levels read the fp32 filter / write the fp32 dk themselves (set False: cast passes around them)
@@ -143,6 +144,17 @@ class SimOps:
             e = int(round(np.log2(lf32)))
             assert 2.0 ** e == lf32 and (inp if fwd else out).dtype == np.float32
             dt = dt | 16 | (e << 8)
+        if n0 in (64, 128) and Llong > 32 * mi:      # the wide form (ffc_outer_pass_all beyond the first 32 long-side rows): 16-bit rows, see _TorchOps.outer
+            base = dt & 15
+            assert not self.half
+            if lf32 is not None and fwd:
+                inp = to_bits(np.asarray(inp, np.float32) * np.float32(lf32), base)
+            tmp = np.zeros(out.shape, np.uint16) if (lf32 is not None and not fwd) else out
+            rc = lib().ffcsim_big_outer_all(n0 // 32, base, int(fwd), p(inp), p(tmp), p(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale))
+            assert rc == 0, rc
+            if tmp is not out:
+                out[...] = from_bits(tmp, base)
+            return
         if n0 in (64, 128) and self.one_launch:      # all R passes in one workgroup run (ffc_outer_pass_all)
             rc = lib().ffcsim_big_outer_all(n0 // 32, dt, int(fwd), p(inp), p(out), p(gate), bv, npair, Hin, mi, Llong, ctypes.c_float(scale))
             assert rc == 0, rc

@@ -159,6 +159,35 @@ def test_flash_fft_conv_gating_padded(B, H, seqlen, dtype):
     run_case(B, H, seqlen, dtype, padded=True, gated=True)
 
 
+@pytest.mark.parametrize("B,H,seqlen,L,dtype,gated", [(2, 8, 2097152, 2097152, torch.bfloat16, True), (1, 4, 4194304, 4194304, torch.float16, False),
+                                                     (3, 4, 4194304, 3000004, torch.bfloat16, True), (2, 6, 2097152, 1500001, torch.float16, True)])
+def test_one_level_at_any_length(B, H, seqlen, L, dtype, gated, monkeypatch):
+    """Round 6, opt-in (FFC_BIG_WIDE=1): fft 2097152 = 64 x 32768 and 4194304 = 128 x 32768 in ONE HBM level for rows beyond N / 2 resp. N / 4 (the wide form
+    of the level, csrc/ffc_big.h BigBody::run_wide; reference: the 128-point butterfly at any length, butterfly_padded_cuda_bf16.cu:302-487).  Rows that are
+    NON-ZERO over their whole length (the reference's own cases zero the second half), ragged lengths incl. L % 8 != 0, odd batch: forward against the
+    torch.fft oracle, every gradient against the default routing (two levels / 32 x 65536: another rounding sequence of the same values)."""
+    from flashfftconv import FlashFFTConv, bigfft, conv as C
+    torch.manual_seed(seqlen + L + B)
+    u = torch.randn(B, H, L, device="cuda").to(dtype) * 0.02
+    k = torch.randn(H, L, device="cuda") * 0.02 * torch.exp(-4.0 * torch.arange(L, device="cuda") / L)
+    gates = [torch.randn_like(u) * 0.5 for _ in range(2)] if gated else []
+    dout = torch.randn_like(u) * 0.02
+    res = {}
+    for wide in (False, True):
+        monkeypatch.setattr(bigfft, "WIDE", wide)
+        fac = bigfft.choose(seqlen, L, C._TorchOps)
+        assert (fac == bigfft.ONE128[seqlen] and bigfft.is_wide(fac[0][0], fac[1], L)) if wide else fac == bigfft.BIG_FACTORS[seqlen]
+        conv = FlashFFTConv(seqlen, dtype=dtype).cuda()
+        leaves = [u.clone().requires_grad_(True), k.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in gates]
+        out = conv(*leaves)
+        res[wide] = (out.detach(), torch.autograd.grad(out, leaves, dout))
+    (ref,) = stable((lambda: (ref_fft_conv(u * gates[0], k, n=seqlen) * gates[1],)) if gated else (lambda: (ref_fft_conv(u, k, n=seqlen),)), "forward")
+    tol = REL[dtype] * BIG_F * (1.5 if gated else 1.0)
+    assert rel(res[True][0], ref) < tol and rel(res[False][0], ref) < tol, (rel(res[True][0], ref), rel(res[False][0], ref))
+    for a, b, what in zip(res[True][1], res[False][1], ("du", "dk", "dpregate", "dpostgate")):
+        assert rel(a, b) < 2 * tol, f"{what}: rel {rel(a, b):.3e}"
+
+
 @pytest.mark.parametrize("B,H,seqlen", [(5, 111, 4096), (3, 111, 32768), (3, 7, 65536), (5, 3, 1048576)])
 def test_odd_batches_gated(B, H, seqlen):
     """odd batch sizes (a half-empty packed pair) are not in the reference matrix"""

@@ -191,3 +191,22 @@ def test_fitted_fft_size_is_the_same_convolution(N, Lu, Lk):
         assert (a - b).norm() < 1e-5 * b.norm()
     if len(res) == 3:
         assert (res[0][0] - res[2][0]).norm() > 1e-2 * res[0][0].norm()
+
+
+def test_level_routing_of_the_2m_and_4m_sizes(monkeypatch):
+    """bigfft.choose: fft 4194304 = 128 x 32768 / 2097152 = 64 x 32768 in ONE level while the rows fit the first 32 long-side rows (L <= N / 4 resp. N / 2);
+    beyond that two levels / the 2-pass inner size -- or, opt-in (FFC_BIG_WIDE=1, round 6), the level's wide form, which stores all rows (no half-row form)."""
+    from flashfftconv import bigfft as BG
+
+    class Ops:
+        HAS_128 = True
+        HAS_WIDE = True
+    monkeypatch.setattr(BG, "WIDE", False)
+    assert BG.choose(4194304, 1048576, Ops) == ((128,), 32768) and BG.choose(4194304, 1048577, Ops) == ((16, 16), 16384)
+    assert BG.choose(2097152, 1048576, Ops) == ((64,), 32768) and BG.choose(2097152, 2097152, Ops) == ((32,), 65536)
+    assert BG.half_ok(4194304, 1, 1048576, Ops) and not BG.half_ok(4194304, 1, 2000000, Ops) and BG.half_ok(2097152, 1, 2097152, Ops)
+    monkeypatch.setattr(BG, "WIDE", True)
+    assert BG.choose(4194304, 4194304, Ops) == ((128,), 32768) and BG.choose(2097152, 1500001, Ops) == ((64,), 32768)
+    assert BG.is_wide(128, 32768, 1048577) and not BG.is_wide(128, 32768, 1048576) and not BG.is_wide(32, 65536, 2097152)
+    assert BG.half_ok(4194304, 1, 1048576, Ops) and not BG.half_ok(4194304, 1, 1048577, Ops) and not BG.half_ok(2097152, 1, 2097152, Ops)
+    assert BG.choose(4194304, 4194304, type("NoWide", (), {"HAS_128": True})) == ((16, 16), 16384)

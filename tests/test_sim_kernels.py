@@ -233,6 +233,45 @@ def test_one_level_of_128(L, B, gated, f):
     assert rel(dk, dkref) < 1.5e-2
 
 
+@pytest.mark.parametrize("L,B,gated,f", [(524288, 2, False, 128), (300004, 1, True, 128), (400008, 3, True, 128), (262144, 1, True, 64), (200001, 2, False, 64)])
+def test_one_level_of_128_at_any_length(L, B, gated, f):
+    """Round 6, the WIDE form of the factor-128 / 64 level (BigBody::run_wide: up to R * 32 long-side rows, an R-point butterfly of the row blocks in front
+    of the pass matrices; how fft 4194304 = 128 x 32768 and 2097152 = 64 x 32768 run at L > N / 4 resp. N / 2) on sizes the simulator finishes:
+    fft 524288 = 128 x 4096 and 262144 = 64 x 4096 with rows up to L = N -- forward (gated, ragged incl. L % 8 != 0, odd batch), k -> k_f and dk."""
+    from flashfftconv import bigfft as BG
+    N, fac = f * 4096, ((f,), 4096)
+    assert L > N // (f // 32)      # beyond the first 32 long-side rows
+    rng = np.random.default_rng(L)
+    dt, H, M = 0, 1, 4096
+    ops = S.SimOps()
+    assert BG.is_wide(f, M, L)
+    u, g1, g2, d = (rng.standard_normal((B, H, L)).astype(np.float32) for _ in range(4))
+    k = (rng.standard_normal((H, L)) * 0.05 * np.exp(-np.arange(L) / (L / 6.0))).astype(np.float32)
+    ub, g1b, g2b, db = (S.to_bits(x, dt) for x in (u, g1, g2, d))
+    kf = BG.kernel_fft(ops, dt, N, k, H, L, fac)
+    x = BG.levels_forward(ops, dt, N, ub, B, H, L, g1b if gated else None, fac)
+    assert x.shape == (2 * ((B + 1) // 2), H * f, M)
+    # the level against its definition: X_{k0}[m] = s W_N^{m k0} sum_{n0} x[n0 M + m] W_f^{n0 k0}, rows stored as c * 32 + d for k0 = c + R d
+    R = f // 32
+    xin = q(u, dt).astype(np.float64) * (q(g1, dt) if gated else 1.0)
+    z = np.zeros((N,), np.complex128)
+    z[:L] = xin[0, 0] + 1j * (xin[1, 0] if B > 1 else 0.0)
+    X = np.fft.fft(z.reshape(f, M), axis=0) * np.exp(-2j * np.pi * np.outer(np.arange(f), np.arange(M)) / N) * BG.level_scale(f)
+    order = [c + R * dd for c in range(R) for dd in range(32)]
+    got = S.from_bits(x[0, :f], dt).astype(np.float64) + 1j * S.from_bits(x[1, :f], dt)
+    assert rel(got, X[order]) < 6e-3, rel(got, X[order])
+    y = ops.conv(dt, M, x, kf, False)
+    out = np.zeros_like(ub)
+    BG.levels_inverse(ops, dt, N, y, out, B, H, L, g2b if gated else None, None, fac)
+    ref = O.ref_fft_conv_gated(q(u, dt), k, q(g1, dt), q(g2, dt), N, dtype="bf16") if gated else O.ref_fft_conv(q(u, dt), k, N)
+    assert rel(S.from_bits(out, dt), ref) < 1.5e-2, rel(S.from_bits(out, dt), ref)
+    xd = BG.levels_forward(ops, dt, N, db, B, H, L, None, fac)
+    xu = BG.levels_forward(ops, dt, N, ub, B, H, L, None, fac)
+    dk = BG.dk_from_slabs(ops, N, ops.dkf(dt, M, xd, xu), xu.shape[0], H, L, None, fac)
+    _, dkref = O.ref_grads(q(u, dt), k, q(d, dt), N)
+    assert rel(dk, dkref) < 1.5e-2, rel(dk, dkref)
+
+
 @pytest.mark.parametrize("N,L,B,H,nch,gated", [(256, 128, 9, 2, 1, True), (1024, 1024, 3, 2, 1, False), (4096, 2048, 5, 2, 2, True),
                                                (16384, 8192, 3, 1, 1, False), (32768, 16384, 3, 2, 2, True)])
 @pytest.mark.parametrize("dt", [0, 1])
